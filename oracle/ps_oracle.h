@@ -1,0 +1,140 @@
+/*
+ * ps_oracle.h -- CPU oracle for the PARA-suite mapping hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under para-suite_amd/ may include, link
+ * or call this.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg use it, and only as the checker.
+ *
+ * PARITY UNPINNED.  The hot path of the reference -- `bwa index`,
+ * `bwa aln` / `bwa parasuite`, `bwa samse`, spawned at
+ * /root/reference/src/src/mapping/PARAsuiteMapping.java:48-53,63-77,85-92 and
+ * BWAMapping.java:38-43,51-61,68-75 -- lives in a third-party dependency that
+ * is NOT in the reference tree (akloetgen/PARA-suite_aligner, a fork of
+ * lh3/bwa pinned only by the log string "BWA 0.7.8",
+ * PARAsuiteMapping.java:52).  The reference holds no tests, golden vectors or
+ * SAM fixtures for this path.  This file therefore restates the *published
+ * upstream algorithm* of BWA 0.7.x `aln`+`samse` (Li & Durbin 2009; file and
+ * function names of upstream bwa are cited for orientation), and for the
+ * PAR-CLIP substitution-aware penalty of `bwa parasuite` -- whose source is
+ * unavailable -- a cost model OF OUR OWN (see orc_profile_costs) that
+ * degenerates to stock BWA when no profile is given.
+ * What is pinned here: glibc's drand48/lrand48 (the RNG the algorithm uses),
+ * a brute-force aligner, and hand-checkable known-answer cases (tests/).
+ */
+#ifndef PS_ORACLE_H
+#define PS_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- options: upstream gap_opt_t (bwtaln.h) + samse -n + our cost model ---- */
+typedef struct {
+    int32_t max_diff;        /* aln -n INT; <0 => use fnr                    */
+    double  fnr;             /* aln -n FLOAT (0.04); <=0 when max_diff fixed */
+    int32_t max_gapo;        /* -o 1  */
+    int32_t max_gape;        /* -e -1 => 6 with MODE_GAPE                    */
+    int32_t mode_gape;       /* 1: gap extensions count as differences       */
+    int32_t indel_end_skip;  /* -i 5  */
+    int32_t max_del_occ;     /* -d 10 */
+    int32_t max_entries;     /* -m 2000000 */
+    int32_t seed_len;        /* -l 32 */
+    int32_t max_seed_diff;   /* -k 2  */
+    int32_t max_top2;        /* -R 30 */
+    int32_t s_mm, s_gapo, s_gape; /* -M 3 -O 11 -E 4 */
+    int32_t n_occ;           /* samse -n 3 */
+    /* PAR-CLIP cost model (ours; profile==0 => stock BWA) */
+    int32_t profile;         /* 0 stock, 1 error-profile weighted            */
+    int32_t unit;            /* U: cost of one average mismatch              */
+    int32_t x_avg_mm;        /* -X: budget in average mismatches; <0 => per-length table */
+    int32_t sub_cost[16];    /* [ref*4+read], read orientation, diag 0       */
+    int32_t n_cost;          /* read base N                                  */
+    int32_t gapo_ins_cost, gapo_del_cost, gape_cost;
+} orc_opt_t;
+
+/* one SA interval hit: upstream bwt_aln1_t (bwtaln.h) + budget units */
+typedef struct {
+    uint64_t k, l;
+    int32_t n_mm, n_gapo, n_gape, n_ins, n_del, score, units, _pad;
+} orc_aln_t;
+
+typedef struct { uint64_t w; int32_t bid; int32_t _pad; } orc_width_t;
+
+/* per-read result of the samse stage (upstream bwa_seq_t fields we report) */
+typedef struct {
+    int64_t  pos;            /* 0-based forward coordinate in the pac, -1 none */
+    uint64_t sa;
+    int32_t  type;           /* 0 none 1 unique 2 repeat (BWA_TYPE_*)          */
+    int32_t  strand, mapq, n_mm, n_gapo, n_gape, ref_shift, score;
+    int32_t  c1, c2, nm, n_cigar, n_multi, flag, seqid, nn;
+    uint32_t cigar[16];      /* len<<4|op, op 0..3 = MIDS                      */
+} orc_hit_t;
+
+typedef struct orc_index orc_index_t;
+
+typedef struct {            /* instrumentation for roofline accounting */
+    uint64_t occ_pairs;      /* (k-1,l) Occ lookups                         */
+    uint64_t occ_same_blk;   /* of which both rows fall in one block        */
+    uint64_t nodes;          /* popped stack entries that were expanded     */
+    uint64_t pushes;
+    uint64_t lf_steps;       /* SA-walk steps                               */
+    uint64_t max_stack;
+} orc_stats_t;
+
+void     orc_default_opt(orc_opt_t *o);
+/* our PAR-CLIP cost rule: fills profile/unit/sub_cost/... from a 4x4 matrix
+ * P[ref][read] (read orientation, ErrorProfiling.java:504-531) and indel rates
+ * (ErrorProfiling.java:545-591).  NaN/0 entries are floored. */
+void     orc_profile_costs(orc_opt_t *o, const double P[16], double ins_rate, double del_rate, int x_avg_mm);
+int      orc_read_profile_files(const char *ep, const char *ip, double P[16], double *ins, double *del);
+int      orc_cal_maxdiff(int l, double err, double thres);
+int      orc_mapq_logn(int n);
+
+/* RNG: restatement of POSIX srand48/drand48/lrand48 (pinned against libc in tests) */
+typedef struct { uint64_t x; } orc_rng_t;
+void     orc_srand48(orc_rng_t *r, long seed);
+double   orc_drand48(orc_rng_t *r);
+long     orc_lrand48(orc_rng_t *r);
+
+/* index */
+orc_index_t *orc_index_from_fasta(const char *fa_path);
+/* adopt an externally built BWT (1 byte/symbol, n symbols, '$' removed) + sampled SA */
+orc_index_t *orc_index_from_parts(const char *fa_path, const uint8_t *bwt_syms, uint64_t n,
+                                  uint64_t primary, const uint64_t *sa_samples, int sa_intv);
+void     orc_index_free(orc_index_t *);
+uint64_t orc_index_seq_len(const orc_index_t *);
+uint64_t orc_index_l_pac(const orc_index_t *);
+uint64_t orc_index_primary(const orc_index_t *);
+void     orc_index_L2(const orc_index_t *, uint64_t out[5]);
+int      orc_index_n_seqs(const orc_index_t *);
+int      orc_index_n_holes(const orc_index_t *);
+const uint8_t *orc_index_pac(const orc_index_t *);
+void     orc_index_bwt_syms(const orc_index_t *, uint8_t *out);           /* n bytes */
+uint64_t orc_index_n_sa(const orc_index_t *);
+void     orc_index_sa_samples(const orc_index_t *, uint64_t *out);
+uint64_t orc_occ(const orc_index_t *, int64_t k, int c);
+uint64_t orc_sa(const orc_index_t *, uint64_t k);
+void     orc_set_block_syms(int syms_per_block);  /* geometry used for occ_same_blk */
+void     orc_stats_reset(void);
+void     orc_stats_get(orc_stats_t *);
+
+/* stage functions on one read; seq codes 0..3 ACGT, 4 N, read orientation */
+int      orc_cal_width(const orc_index_t *, int len, const uint8_t *rev_read, orc_width_t *width);
+/* returns n_aln; out must hold cap entries (extra hits are counted, not stored) */
+int      orc_aln_one(const orc_index_t *, const orc_opt_t *, int len, const uint8_t *read,
+                     orc_aln_t *out, int cap, orc_width_t *width_out, orc_width_t *seed_width_out);
+int      orc_ksw_global(int qlen, const uint8_t *q, int tlen, const uint8_t *t, int w,
+                        uint32_t *cigar, int cap);
+
+/* whole pipeline: FASTQ -> SAM (alignment lines exactly as upstream bwa_print_sam1;
+ * header @SQ lines, no @PG).  hits (optional) gets one record per read.
+ * sai_out (optional): file receiving per read int32 n_aln + n_aln*orc_aln_t.   */
+int64_t  orc_map_fastq(const orc_index_t *, const orc_opt_t *, const char *fastq, const char *sam_out,
+                       const char *sai_out, orc_hit_t *hits, int64_t hits_cap, int n_threads,
+                       double *t_aln_s, double *t_samse_s);
+const char *orc_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
