@@ -1,0 +1,507 @@
+// ps_core.h -- per-lane device logic of the mapping hot path (gfx950 kernels
+// in ps_kernels.hip wrap these; tests/hostsim runs the same functions lane by
+// lane on the host as a debugging aid -- it is not a product path).
+//
+// Algorithms: FM-index backward search with bounded best-first backtracking
+// (what `bwa aln` / `bwa parasuite` compute for
+// /root/reference/src/src/mapping/PARAsuiteMapping.java:63-77 and
+// BWAMapping.java:51-61), suffix-array interval -> text position and banded
+// global alignment of gapped hits (`bwa samse`, PARAsuiteMapping.java:85-92).
+// One read per lane; every loop iteration of a lane performs at most one
+// Occ-block pair lookup so that all 64 lanes of a wave keep their random
+// 64-byte HBM loads in flight together.
+#pragma once
+#include "ps_types.h"
+
+namespace ps {
+
+// ------------------------------------------------------------ popcounts ---
+PS_HD uint32_t ps_popc(uint32_t x)
+{
+#ifdef __HIP_DEVICE_COMPILE__
+    return (uint32_t)__popc(x);
+#else
+    return (uint32_t)__builtin_popcount(x);
+#endif
+}
+PS_HD uint32_t pfx_mask(int ns) // low-bit-of-pair mask covering the first ns symbols of a word
+{
+    return ns >= 16 ? 0x55555555u : (ns <= 0 ? 0u : (((1u << (2 * ns)) - 1u) & 0x55555555u));
+}
+
+struct Blk { uint32_t x[16]; };  // cnt[4] + sym[12]
+
+PS_HD void load_blk(const OccBlock *blocks, uint32_t b, Blk &o)
+{
+#ifdef __HIP_DEVICE_COMPILE__
+    const uint4 *p = reinterpret_cast<const uint4 *>(blocks + b);
+    uint4 a = p[0], c = p[1], d = p[2], e = p[3];
+    o.x[0] = a.x; o.x[1] = a.y; o.x[2] = a.z; o.x[3] = a.w;
+    o.x[4] = c.x; o.x[5] = c.y; o.x[6] = c.z; o.x[7] = c.w;
+    o.x[8] = d.x; o.x[9] = d.y; o.x[10] = d.z; o.x[11] = d.w;
+    o.x[12] = e.x; o.x[13] = e.y; o.x[14] = e.z; o.x[15] = e.w;
+#else
+    const uint32_t *p = reinterpret_cast<const uint32_t *>(blocks + b);
+    for (int j = 0; j < 16; ++j) o.x[j] = p[j];
+#endif
+}
+
+// occurrences of every symbol among the first r (1..192) symbols of the block, plus the block base
+PS_HD void blk_count4(const Blk &b, int r, uint32_t cnt[4])
+{
+    uint32_t c1 = 0, c2 = 0, c3 = 0;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+        uint32_t w = b.x[4 + j], m = pfx_mask(r - 16 * j);
+        uint32_t lo = w & m, hi = (w >> 1) & m;
+        c3 += ps_popc(lo & hi);
+        c2 += ps_popc(hi & ~lo);
+        c1 += ps_popc(lo & ~hi);
+    }
+    cnt[0] = b.x[0] + ((uint32_t)r - c1 - c2 - c3);
+    cnt[1] = b.x[1] + c1; cnt[2] = b.x[2] + c2; cnt[3] = b.x[3] + c3;
+}
+PS_HD uint32_t blk_count1(const Blk &b, int r, int c)
+{
+    uint32_t n = 0, pat = 0x55555555u * (uint32_t)(3 - c); // XOR makes symbol c read 11
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+        uint32_t w = b.x[4 + j] ^ pat, m = pfx_mask(r - 16 * j);
+        n += ps_popc(w & (w >> 1) & m);
+    }
+    uint32_t base = c == 0 ? b.x[0] : (c == 1 ? b.x[1] : (c == 2 ? b.x[2] : b.x[3]));
+    return base + n;
+}
+PS_HD int blk_sym(const Blk &b, int pos) // symbol pos (0..191) of the block
+{
+    uint32_t w = 0; int wi = pos >> 4;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) w = (j == wi) ? b.x[4 + j] : w;
+    return (int)((w >> (2 * (pos & 15))) & 3u);
+}
+
+// build one block from up to 192 symbols (codes 0..3) and the running counts before it
+PS_HD void blk_pack(OccBlock &b, const uint8_t *syms, int n, const uint32_t cnt[4])
+{
+    for (int c = 0; c < 4; ++c) b.cnt[c] = cnt[c];
+    for (int j = 0; j < 12; ++j) {
+        uint32_t w = 0;
+        for (int t = 0; t < 16; ++t) { int p = j * 16 + t; if (p < n) w |= (uint32_t)(syms[p] & 3) << (2 * t); }
+        b.sym[j] = w;
+    }
+}
+
+// row (0..n) of the BW matrix of T$ -> index into the stored BWT (the '$' row is not stored)
+PS_HD bwtint row_to_stored(const IndexView &ix, bwtint row) { return row - (row >= ix.primary ? 1u : 0u); }
+
+struct LaneStats { uint32_t pairs, same, nodes, pushes, pops, iters, exact, lf; };
+
+// Occ(k-1, .) and Occ(l, .) for all four symbols: the memory operation of one search step.
+PS_HD void occ_pair4(const IndexView &ix, bwtint k, bwtint l, uint32_t ck[4], uint32_t cl[4], LaneStats &st)
+{
+    bwtint sl = row_to_stored(ix, l), bl = sl / PS_BLK_SYMS;
+    bwtint sk = 0, bk = bl;
+    bool need_k = k != 0;
+    if (need_k) { sk = row_to_stored(ix, k - 1); bk = sk / PS_BLK_SYMS; }
+    Blk xl, xk;
+    load_blk(ix.blocks, bl, xl);
+    bool other = need_k && bk != bl;
+    if (other) load_blk(ix.blocks, bk, xk);
+    blk_count4(xl, (int)(sl - bl * PS_BLK_SYMS) + 1, cl);
+    if (!need_k) { ck[0] = ck[1] = ck[2] = ck[3] = 0; }
+    else if (other) blk_count4(xk, (int)(sk - bk * PS_BLK_SYMS) + 1, ck);
+    else blk_count4(xl, (int)(sk - bk * PS_BLK_SYMS) + 1, ck);
+    ++st.pairs;
+    if (need_k && !other) ++st.same;
+}
+PS_HD void occ_pair1(const IndexView &ix, bwtint k, bwtint l, int c, uint32_t &ok, uint32_t &ol, LaneStats &st)
+{
+    bwtint sl = row_to_stored(ix, l), bl = sl / PS_BLK_SYMS;
+    bwtint sk = 0, bk = bl;
+    bool need_k = k != 0;
+    if (need_k) { sk = row_to_stored(ix, k - 1); bk = sk / PS_BLK_SYMS; }
+    Blk xl, xk;
+    load_blk(ix.blocks, bl, xl);
+    bool other = need_k && bk != bl;
+    if (other) load_blk(ix.blocks, bk, xk);
+    ol = blk_count1(xl, (int)(sl - bl * PS_BLK_SYMS) + 1, c);
+    if (!need_k) ok = 0;
+    else if (other) ok = blk_count1(xk, (int)(sk - bk * PS_BLK_SYMS) + 1, c);
+    else ok = blk_count1(xl, (int)(sk - bk * PS_BLK_SYMS) + 1, c);
+    ++st.pairs;
+    if (need_k && !other) ++st.same;
+}
+
+// ------------------------------------------------------------ read access --
+PS_HD int read_base(const uint32_t *bases, const uint32_t *nmask, int n_reads, int r, int j) // 0..3, 4 = N
+{
+    uint32_t w = bases[(size_t)(j >> 4) * n_reads + r];
+    uint32_t m = nmask[(size_t)(j >> 5) * n_reads + r];
+    return ((m >> (j & 31)) & 1u) ? 4 : (int)((w >> (2 * (j & 15))) & 3u);
+}
+
+// compact width byte: low 7 bits = min(bid,127), bit 7 = (w[i-1] == w[i])
+PS_HD uint8_t cw_pack(int bid, bool eq) { return (uint8_t)((bid > 127 ? 127 : bid) | (eq ? 0x80 : 0)); }
+
+// --------------------------------------------------------- width chains ---
+// Lower bound D(i) on the differences needed for the read's last i+1 bases
+// (what upstream's bwt_cal_width returns), computed by restartable exact
+// backward search.  One chain = (k,l,bid); the kernel steps the full-read chain
+// and the seed chain together so a lane keeps two independent loads in flight.
+struct WChain { bwtint k, l; int bid; uint32_t prev_w; };
+PS_HD void wchain_init(const IndexView &ix, WChain &c) { c.k = 0; c.l = ix.seq_len; c.bid = 0; c.prev_w = 0xFFFFFFFFu; }
+PS_HD void wchain_step(const IndexView &ix, WChain &c, int base, uint32_t &w_out, uint8_t &cw_out, bool first, LaneStats &st)
+{
+    if (base < 4) {
+        uint32_t ok, ol;
+        occ_pair1(ix, c.k, c.l, base, ok, ol, st);
+        c.k = ix.L2[base] + ok + 1;
+        c.l = ix.L2[base] + ol;
+    }
+    if (c.k > c.l || base > 3) { c.k = 0; c.l = ix.seq_len; ++c.bid; }
+    uint32_t w = c.l - c.k + 1;
+    w_out = w;
+    cw_out = cw_pack(c.bid, !first && w == c.prev_w);
+    c.prev_w = w;
+}
+
+// ----------------------------------------------------- backtracking lane ---
+enum { M_FETCH = 0, M_POP = 1, M_EXACT = 2, M_EXPAND = 3, M_EXIT = 4 };
+
+struct BtLane {
+    int r, mode;
+    // current entry (held in registers; "virtually" on the stack when have_cur)
+    bwtint k, l;
+    int i, score, units, n_mm, n_gapo, n_gape, n_ins, n_del, state, ldp;
+    bool have_cur;
+    int best_score, max_units, n_aln, n_stack, status;
+    unsigned long long best_cnt;
+    unsigned long long bm[2];  // non-empty score buckets
+    uint32_t bump, free_head;
+    LaneStats st;
+};
+
+// local per-lane memory (LDS in the kernel): cw[len+1], csw[seed_len+1], seq[len]
+PS_HD int lm_bytes(int len, int seed_len) { int n = (len + 1) + (seed_len + 1) + len; n = (n + 3) & ~3; if (((n >> 2) & 1) == 0) n += 4; return n; }
+
+struct BtMem {              // views of one lane's slices
+    uint8_t *cw, *csw, *seq;
+    Entry *pool; uint32_t *heads;
+};
+
+PS_HD void store_entry(Entry *dst, const Entry &e)
+{
+#ifdef __HIP_DEVICE_COMPILE__
+    const uint4 *s = reinterpret_cast<const uint4 *>(&e);
+    uint4 *d = reinterpret_cast<uint4 *>(dst);
+    d[0] = s[0]; d[1] = s[1];
+#else
+    *dst = e;
+#endif
+}
+PS_HD void load_entry(const Entry *src, Entry &e)
+{
+#ifdef __HIP_DEVICE_COMPILE__
+    const uint4 *s = reinterpret_cast<const uint4 *>(src);
+    uint4 *d = reinterpret_cast<uint4 *>(&e);
+    d[0] = s[0]; d[1] = s[1];
+#else
+    e = *src;
+#endif
+}
+
+PS_HD bool bm_test(const BtLane &L, int b) { return (L.bm[b >> 6] >> (b & 63)) & 1ull; }
+PS_HD void bm_set(BtLane &L, int b) { L.bm[b >> 6] |= 1ull << (b & 63); }
+PS_HD void bm_clr(BtLane &L, int b) { L.bm[b >> 6] &= ~(1ull << (b & 63)); }
+PS_HD int bm_first(const BtLane &L)
+{
+#ifdef __HIP_DEVICE_COMPILE__
+    return L.bm[0] ? (__ffsll((unsigned long long)L.bm[0]) - 1) : (64 + __ffsll((unsigned long long)L.bm[1]) - 1);
+#else
+    return L.bm[0] ? __builtin_ctzll(L.bm[0]) : 64 + __builtin_ctzll(L.bm[1]);
+#endif
+}
+
+// push a child entry on its score bucket (LIFO linked list through Entry::next)
+PS_HD void bt_push(const BtArgs &a, BtLane &L, BtMem &m, int i, bwtint k, bwtint l, int n_mm, int n_gapo, int n_gape,
+                   int n_ins, int n_del, int state, bool is_diff, int score, int units)
+{
+    if (units > L.max_units) return;        // cannot be afforded (no-op with stock costs)
+    uint32_t idx;
+    if (L.free_head != PS_NIL) { idx = L.free_head; L.free_head = m.pool[idx].next; }
+    else if (L.bump < a.pool_cap) idx = L.bump++;
+    else { L.status = RS_OVERFLOW_POOL; return; }
+    Entry e;
+    e.k = k; e.l = l; e.score = (uint16_t)score; e.units = (uint16_t)units;
+    e.i = (uint8_t)i; e.last_diff_pos = (uint8_t)(is_diff ? i : 0);
+    e.n_mm = (uint8_t)n_mm; e.n_gapo = (uint8_t)n_gapo; e.n_gape = (uint8_t)n_gape;
+    e.n_ins = (uint8_t)n_ins; e.n_del = (uint8_t)n_del; e.state = (uint8_t)state;
+    e.next = bm_test(L, score) ? m.heads[score] : PS_NIL;
+    e.pad[0] = e.pad[1] = 0;
+    store_entry(&m.pool[idx], e);
+    m.heads[score] = idx;
+    bm_set(L, score);
+    ++L.n_stack; ++L.st.pushes;
+}
+
+PS_HD void bt_finish_read(const BtArgs &a, BtLane &L)
+{
+    a.n_aln[L.r] = L.n_aln;
+    a.status[L.r] = (uint8_t)L.status;
+    L.mode = M_FETCH;
+}
+
+// a hit: SA interval [k,l] reached with the current entry's edit counts (upstream bwt_match_gap's hit block)
+PS_HD void bt_hit(const BtArgs &a, BtLane &L, BtMem &m)
+{
+    const Model &md = a.md;
+    if (L.n_aln == 0) {
+        L.best_score = L.score;
+        int t = L.units + md.u_tight;
+        L.max_units = t > md.max_units ? md.max_units : t;
+    }
+    if (L.score == L.best_score) L.best_cnt += (unsigned long long)(L.l - L.k) + 1ull;
+    else if (L.best_cnt > (unsigned long long)md.max_top2) { bt_finish_read(a, L); return; }
+    bool do_add = true;
+    AlnRec *out = a.alns + (size_t)L.r * a.aln_cap;
+    if (L.n_gapo) {
+        for (int j = 0; j < L.n_aln; ++j)
+            if (out[j].k == L.k && out[j].l == L.l) { do_add = false; break; }
+    }
+    if (!do_add) return;
+    // shadow: discount this hit's occurrences from the width bounds left of the last difference
+    {
+        uint32_t x = L.l - L.k + 1, j = 0, prev = 0;
+        int lim = L.ldp;
+        for (int i = 0; i < lim; ++i) {
+            size_t off = (size_t)i * a.n_reads + L.r;
+            uint32_t w = a.w[off];
+            int bid = m.cw[i] & 0x7f;
+            if (w > x) { w -= x; a.w[off] = w; }
+            else if (w == x) { bid = 1; w = a.ix.seq_len - (++j); a.w[off] = w; }
+            m.cw[i] = cw_pack(bid, i > 0 && w == prev);
+            prev = w;
+        }
+        if (lim > 0) {
+            uint32_t w = a.w[(size_t)lim * a.n_reads + L.r];
+            m.cw[lim] = cw_pack(m.cw[lim] & 0x7f, w == prev);
+        }
+    }
+    if (L.n_aln >= a.aln_cap) { L.status = RS_OVERFLOW_ALN; bt_finish_read(a, L); return; }
+    AlnRec rec;
+    rec.k = L.k; rec.l = L.l; rec.score = (uint16_t)L.score; rec.units = (uint16_t)L.units;
+    rec.n_mm = (uint8_t)L.n_mm; rec.n_gapo = (uint8_t)L.n_gapo; rec.n_gape = (uint8_t)L.n_gape;
+    rec.n_ins = (uint8_t)L.n_ins; rec.n_del = (uint8_t)L.n_del; rec.pad[0] = rec.pad[1] = rec.pad[2] = 0;
+    out[L.n_aln++] = rec;
+}
+
+// One iteration of a lane.  next_r: the read this lane takes when it needs one (caller advances it).
+PS_HD void bt_iter(const BtArgs &a, BtLane &L, BtMem &m, int &next_r, int r_stride)
+{
+    const Model &md = a.md;
+    const int len = a.len;
+    ++L.st.iters;
+    if (L.mode == M_FETCH) {
+        int r = next_r;
+        if (r >= a.n_reads) { L.mode = M_EXIT; return; }
+        next_r += r_stride;
+        L.r = r; L.status = RS_OK; L.n_aln = 0;
+        // load compact widths and the reverse-complemented read into local memory
+        for (int p = 0; p <= len; ++p) m.cw[p] = a.cwb[(size_t)p * a.n_reads + r];
+        if (md.use_seed) for (int p = 0; p <= md.seed_len; ++p) m.csw[p] = a.cswb[(size_t)p * a.n_reads + r];
+        int nNu = 0;
+        for (int j = 0; j < len; ++j) {
+            int b = read_base(a.bases, a.nmask, a.n_reads, r, len - 1 - j);
+            int c = b > 3 ? 4 : 3 - b;
+            m.seq[j] = (uint8_t)c;
+            if (c > 3) nNu += md.u_mm[4][0];
+        }
+        if (nNu > md.max_units) { bt_finish_read(a, L); return; }
+        L.k = 0; L.l = a.ix.seq_len; L.i = len; L.score = 0; L.units = 0;
+        L.n_mm = L.n_gapo = L.n_gape = L.n_ins = L.n_del = 0; L.state = ST_M; L.ldp = 0;
+        L.have_cur = true; L.n_stack = 0; L.bm[0] = L.bm[1] = 0; L.bump = 0; L.free_head = PS_NIL;
+        L.best_score = 1 << 29; L.max_units = md.max_units; L.best_cnt = 0;
+        L.mode = M_POP;
+    }
+    if (L.mode == M_POP) {
+        int n_virtual = L.n_stack + (L.have_cur ? 1 : 0);
+        if (n_virtual == 0 || n_virtual > md.max_entries || L.status != RS_OK) { bt_finish_read(a, L); return; }
+        if (L.have_cur) L.have_cur = false;
+        else {
+            int b = bm_first(L);
+            uint32_t h = m.heads[b];
+            Entry e;
+            load_entry(&m.pool[h], e);
+            if (e.next == PS_NIL) bm_clr(L, b); else m.heads[b] = e.next;
+            m.pool[h].next = L.free_head; L.free_head = h;
+            --L.n_stack; ++L.st.pops;
+            L.k = e.k; L.l = e.l; L.i = e.i; L.score = e.score; L.units = e.units;
+            L.n_mm = e.n_mm; L.n_gapo = e.n_gapo; L.n_gape = e.n_gape; L.n_ins = e.n_ins; L.n_del = e.n_del;
+            L.state = e.state; L.ldp = e.last_diff_pos;
+        }
+        if (L.score > L.best_score + md.s_stop) { bt_finish_read(a, L); return; }
+        int rem = L.max_units - L.units;
+        if (rem < 0) return;
+        int mleft = md.c_min == 1 ? rem : rem / md.c_min;
+        if (L.i > 0 && mleft < (int)(m.cw[L.i - 1] & 0x7f)) return;
+        if (L.i == 0) { bt_hit(a, L, m); return; }
+        if (mleft == 0 && (L.state == ST_M || md.mode_gape || L.n_gape == md.max_gape)) L.mode = M_EXACT;
+        else L.mode = M_EXPAND;
+    }
+    if (L.mode == M_EXACT) {          // no difference left: extend exactly, one base per iteration
+        int c = m.seq[L.i - 1];
+        ++L.st.exact;
+        if (c > 3) { L.mode = M_POP; return; }
+        uint32_t ok, ol;
+        occ_pair1(a.ix, L.k, L.l, c, ok, ol, L.st);
+        bwtint nk = a.ix.L2[c] + ok + 1, nl = a.ix.L2[c] + ol;
+        if (nk > nl) { L.mode = M_POP; return; }
+        L.k = nk; L.l = nl; --L.i;
+        if (L.i == 0) { L.mode = M_POP; bt_hit(a, L, m); }
+        return;
+    }
+    if (L.mode == M_EXPAND) {
+        int i = L.i - 1;
+        uint32_t ck[4], cl[4];
+        ++L.st.nodes;
+        occ_pair4(a.ix, L.k, L.l, ck, cl, L.st);
+        bwtint occ = L.l - L.k + 1;
+        int rem = L.max_units - L.units;
+        int mleft = md.c_min == 1 ? rem : rem / md.c_min;
+        int ndiff = L.n_mm + L.n_gapo + (md.mode_gape ? L.n_gape : 0);
+        int m_seed = md.max_seed_diff - ndiff;
+        bool allow_diff = true, allow_M = true;
+        if (i > 0) {
+            int b1 = m.cw[i - 1] & 0x7f, b0 = m.cw[i] & 0x7f;
+            bool eq = (m.cw[i] & 0x80) != 0;
+            if (b1 > mleft - 1) allow_diff = false;
+            else if (b1 == mleft - 1 && b0 == mleft - 1 && eq) allow_M = false;
+            if (md.use_seed) {
+                int ii = i - (len - md.seed_len);
+                if (ii > 0) {
+                    int s1 = m.csw[ii - 1] & 0x7f, s0 = m.csw[ii] & 0x7f;
+                    bool seq_ = (m.csw[ii] & 0x80) != 0;
+                    if (s1 > m_seed - 1) allow_diff = false;
+                    else if (s1 == m_seed - 1 && s0 == m_seed - 1 && seq_) allow_M = false;
+                }
+            }
+        }
+        const int e_mm = L.n_mm, e_go = L.n_gapo, e_ge = L.n_gape, e_ni = L.n_ins, e_nd = L.n_del;
+        const int e_sc = L.score, e_un = L.units, e_st = L.state;
+        const bwtint ek = L.k, el = L.l;
+        int tmp = e_go + e_ge;
+        if (allow_diff && i >= md.indel_end_skip + tmp && len - i >= md.indel_end_skip + tmp) {
+            if (e_st == ST_M) {
+                if (e_go < md.max_gapo) {
+                    bt_push(a, L, m, i, ek, el, e_mm, e_go + 1, e_ge, e_ni + 1, e_nd, ST_I, true, e_sc + md.s_gapo_ins, e_un + md.u_gapo_ins);
+                    for (int j = 0; j < 4; ++j) {
+                        bwtint nk = a.ix.L2[j] + ck[j] + 1, nl = a.ix.L2[j] + cl[j];
+                        if (nk <= nl) bt_push(a, L, m, i + 1, nk, nl, e_mm, e_go + 1, e_ge, e_ni, e_nd + 1, ST_D, true, e_sc + md.s_gapo_del, e_un + md.u_gapo_del);
+                    }
+                }
+            } else if (e_st == ST_I) {
+                if (e_ge < md.max_gape)
+                    bt_push(a, L, m, i, ek, el, e_mm, e_go, e_ge + 1, e_ni + 1, e_nd, ST_I, true, e_sc + md.s_gape, e_un + md.u_gape);
+            } else {
+                if (e_ge < md.max_gape && ((e_ge + e_go) * md.u_tight < L.max_units || occ < (bwtint)md.max_del_occ)) {
+                    for (int j = 0; j < 4; ++j) {
+                        bwtint nk = a.ix.L2[j] + ck[j] + 1, nl = a.ix.L2[j] + cl[j];
+                        if (nk <= nl) bt_push(a, L, m, i + 1, nk, nl, e_mm, e_go, e_ge + 1, e_ni, e_nd + 1, ST_D, true, e_sc + md.s_gape, e_un + md.u_gape);
+                    }
+                }
+            }
+        }
+        int s = m.seq[i];
+        L.mode = M_POP;
+        if (allow_diff && allow_M) {
+            for (int j = 1; j <= 4; ++j) {
+                int c = (s + j) & 3;
+                bool is_mm = (j != 4 || s > 3);
+                bwtint nk = a.ix.L2[c] + ck[c] + 1, nl = a.ix.L2[c] + cl[c];
+                if (nk > nl) continue;
+                if (is_mm) bt_push(a, L, m, i, nk, nl, e_mm + 1, e_go, e_ge, e_ni, e_nd, ST_M, true, e_sc + md.s_mm[s][c], e_un + md.u_mm[s][c]);
+                else { // the match child has the parent's score and is pushed last: it is the next pop
+                    L.k = nk; L.l = nl; L.i = i; L.state = ST_M; L.ldp = 0; L.have_cur = true;
+                }
+            }
+        } else if (s < 4) {
+            bwtint nk = a.ix.L2[s] + ck[s] + 1, nl = a.ix.L2[s] + cl[s];
+            if (nk <= nl) { L.k = nk; L.l = nl; L.i = i; L.state = ST_M; L.ldp = 0; L.have_cur = true; }
+        }
+        return;
+    }
+}
+
+// ------------------------------------------------------- SA row -> text ---
+// Walk LF until a sampled row (upstream bwt_sa): one block load per step.
+PS_HD bool sa_walk_step(const IndexView &ix, bwtint &row, uint32_t &steps, LaneStats &st)
+{
+    if ((row & (bwtint)(ix.sa_intv - 1)) == 0) return false;
+    ++steps; ++st.lf;
+    if (row == ix.primary) { row = 0; return true; }
+    bwtint s = row_to_stored(ix, row), b = s / PS_BLK_SYMS;
+    int pos = (int)(s - b * PS_BLK_SYMS);
+    Blk x;
+    load_blk(ix.blocks, b, x);
+    int c = blk_sym(x, pos);
+    row = ix.L2[c] + blk_count1(x, pos + 1, c);
+    return true;
+}
+
+// ------------------------------------------- banded global alignment (DP) --
+// Restates the banded affine-gap global alignment `bwa samse` runs on gapped
+// hits (match 1, mismatch -3, N -1, open 5, extend 1; band w).  H/E rows live
+// in fast per-lane memory (LDS in the kernel, stride hs), the 1-byte traceback
+// matrix z in global memory (stride zs, lane-interleaved).  Returns n_cigar;
+// cigar[j] = len<<4|op (0 M, 1 I, 2 D), at most cap entries.
+PS_HD int pac_base(const uint8_t *pac, bwtint p) { return (pac[p >> 2] >> ((~p & 3u) << 1)) & 3; }
+
+template <class QF>
+PS_HD int banded_global(int qlen, QF query, int tlen, const uint8_t *pac, bwtint rb, int w,
+                        int32_t *H, int32_t *E, int hs, uint8_t *z, size_t zs, uint32_t *cigar, int cap)
+{
+    const int NEG = -0x40000000, gapo = 5, gape = 1, gapoe = 6;
+    int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1, j;
+    H[0] = 0; E[0] = NEG;
+    for (j = 1; j <= qlen && j <= w; ++j) { H[j * hs] = -(gapo + gape * j); E[j * hs] = NEG; }
+    for (; j <= qlen; ++j) H[j * hs] = E[j * hs] = NEG;
+    for (int i = 0; i < tlen; ++i) {
+        int32_t f = NEG, h1;
+        int beg = i > w ? i - w : 0, end = i + w + 1 < qlen ? i + w + 1 : qlen;
+        int t = pac_base(pac, rb + (bwtint)i);
+        h1 = beg == 0 ? -(gapo + gape * (i + 1)) : NEG;
+        for (j = beg; j < end; ++j) {
+            int32_t h = H[j * hs], e = E[j * hs];
+            int q = query(j);
+            uint8_t d;
+            H[j * hs] = h1;
+            h += q > 3 ? -1 : (q == t ? 1 : -3);
+            d = h >= e ? 0 : 1; h = h >= e ? h : e;
+            d = h >= f ? d : 2; h = h >= f ? h : f;
+            h1 = h;
+            h -= gapoe; e -= gape;
+            d |= e > h ? 1 << 2 : 0; e = e > h ? e : h;
+            E[j * hs] = e;
+            f -= gape;
+            d |= f > h ? 2 << 4 : 0; f = f > h ? f : h;
+            z[((size_t)i * n_col + (j - beg)) * zs] = d;
+        }
+        H[end * hs] = h1; E[end * hs] = NEG;
+    }
+    int n = 0, which = 0, i = tlen - 1, k = (i + w + 1 < qlen ? i + w + 1 : qlen) - 1;
+#define PS_PUSHC(OP, LEN) do { if (n && (cigar[n - 1] & 0xfu) == (uint32_t)(OP)) cigar[n - 1] += (uint32_t)(LEN) << 4; \
+        else if (n < cap) cigar[n++] = ((uint32_t)(LEN) << 4) | (uint32_t)(OP); } while (0)
+    while (i >= 0 && k >= 0) {
+        which = (z[((size_t)i * n_col + (k - (i > w ? i - w : 0))) * zs] >> (which << 1)) & 3;
+        if (which == 0) { PS_PUSHC(0, 1); --i; --k; }
+        else if (which == 1) { PS_PUSHC(2, 1); --i; }
+        else { PS_PUSHC(1, 1); --k; }
+    }
+    if (i >= 0) PS_PUSHC(2, i + 1);
+    if (k >= 0) PS_PUSHC(1, k + 1);
+#undef PS_PUSHC
+    for (int a = 0; a < n >> 1; ++a) { uint32_t t = cigar[a]; cigar[a] = cigar[n - 1 - a]; cigar[n - 1 - a] = t; }
+    return n;
+}
+
+}  // namespace ps

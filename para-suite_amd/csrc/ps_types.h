@@ -1,0 +1,98 @@
+// ps_types.h -- plain data shared by host code and gfx950 kernels.
+//
+// Hot path replaced: the `bwa parasuite` / `bwa aln` + `bwa samse` child
+// processes spawned by /root/reference/src/src/mapping/PARAsuiteMapping.java:63-92
+// and BWAMapping.java:51-75.  Data layout is this project's own (the Java side
+// only probes that <ref>.bwt exists, PARAsuiteMapping.java:45-46).
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __HIPCC__
+#define PS_HD __host__ __device__ __forceinline__
+#else
+#define PS_HD inline
+#endif
+
+namespace ps {
+
+// Row / text coordinate.  Round 1: one BWT of forward+reverse-complement text
+// with 2*l_pac < 2^32-1 (genomes up to ~2.1 Gbp); hg19 (n = 6.27e9) needs the
+// 40-bit variant planned in DESIGN.md.
+typedef uint32_t bwtint;
+static const bwtint PS_NIL_ROW = 0xFFFFFFFFu;
+
+// ---- FM index: one 64-byte block per 192 BWT symbols --------------------
+// cnt[c] = occurrences of c in all earlier blocks; sym = 12 words x 16
+// symbols, symbol j of a word at bits [2j,2j+1].  64 B = one HBM burst pair /
+// half an L2 line; 5.33 bits per base.
+static const int PS_BLK_SYMS = 192;
+struct OccBlock { uint32_t cnt[4]; uint32_t sym[12]; };
+
+struct IndexView {
+    const OccBlock *blocks;   // n_blocks
+    const bwtint   *sa;       // SA[row] for row % sa_intv == 0 (row over T$: n+1 rows); sa[0] = 0xFFFFFFFF
+    const uint8_t  *pac;      // forward strand, 2 bit, base p at byte p>>2, bits ((~p)&3)<<1
+    bwtint seq_len;           // n = 2*l_pac
+    bwtint primary;           // row of the '$' character in the last column
+    bwtint l_pac;
+    bwtint L2[5];
+    uint32_t n_blocks, n_sa;
+    int sa_intv;
+};
+
+// ---- cost model for one read length (host fills, kernels read) ----------
+// Stock BWA: every edit costs 1 budget unit; scores 3/11/4.  PAR-CLIP profile
+// mode: units == score == profile-derived integer cost (our model; oracle/ps_oracle.h).
+struct Model {
+    uint8_t u_mm[5][4], s_mm[5][4];   // [search-orientation read code][text char]
+    int32_t u_gapo_ins, s_gapo_ins, u_gapo_del, s_gapo_del, u_gape, s_gape;
+    int32_t s_stop, u_tight, c_min, max_units, n_buckets;
+    int32_t max_gapo, max_gape, mode_gape, indel_end_skip, max_del_occ, max_entries;
+    int32_t seed_len, max_seed_diff, max_top2, use_seed, len;
+};
+static const int PS_MAX_BUCKETS = 128;
+static const int PS_MAX_LEN = 250;
+
+// ---- backtracking stack entry (32 B, two 16-B stores) --------------------
+struct Entry {
+    bwtint k, l;
+    uint16_t score, units;
+    uint8_t i, last_diff_pos, n_mm, n_gapo, n_gape, n_ins, n_del, state;
+    uint32_t next;
+    uint32_t pad[2];
+};
+static const uint32_t PS_NIL = 0xFFFFFFFFu;
+enum { ST_M = 0, ST_I = 1, ST_D = 2 };
+
+// one SA-interval hit (what upstream keeps in a .sai record)
+struct AlnRec {
+    bwtint k, l;
+    uint16_t score, units;
+    uint8_t n_mm, n_gapo, n_gape, n_ins, n_del, pad[3];
+};  // 20 B
+
+enum { RS_OK = 0, RS_OVERFLOW_POOL = 1, RS_OVERFLOW_ALN = 2 };
+
+struct KStats {            // per-launch counters (roofline accounting)
+    unsigned long long occ_pairs, occ_same_blk, nodes, pushes, pops, lf_steps, iters, exact_steps;
+};
+
+// per-batch device state of the backtracking stage (all SoA over reads, or per lane)
+struct BtArgs {
+    IndexView ix;
+    Model md;
+    int n_reads, len, n_lanes;
+    // reads: 2-bit bases [w][n_reads] (base j of a read: word j>>4, bits 2*(j&15)), N mask [j>>5][n_reads]
+    const uint32_t *bases; const uint32_t *nmask; int n_bw, n_mw;
+    // from the width kernel, [pos][n_reads]: interval sizes w (updated by hit shadowing), compact
+    // width bytes cwb (bid | eq<<7) for the read and cswb for its seed
+    uint32_t *w; const uint8_t *cwb; const uint8_t *cswb;
+    // outputs
+    AlnRec *alns; int aln_cap; int32_t *n_aln; uint8_t *status;
+    // per-lane scratch
+    Entry *pool; uint32_t pool_cap; uint32_t *heads;   // heads[lane*PS_MAX_BUCKETS + bucket]
+    KStats *stats;
+};
+
+}  // namespace ps

@@ -1,0 +1,154 @@
+// hostsim.cpp -- TEST HARNESS ONLY (never linked into libparasuite_hip.so).
+// Runs the per-lane device logic of para-suite_amd/csrc/ps_core.h on the host,
+// lane by lane, so that the CPU test tier can compare the exact kernel state
+// machine with the oracle without a GPU.  The index blocks are packed here
+// from a BWT symbol string supplied by the test (the oracle's), which also
+// pins the block layout.
+#include "../../para-suite_amd/csrc/ps_core.h"
+#include "../../para-suite_amd/csrc/ps_model.h"
+#include <vector>
+#include <cstring>
+#include <cstdlib>
+using namespace ps;
+
+struct SimIndex {
+    std::vector<OccBlock> blocks; std::vector<bwtint> sa; std::vector<uint8_t> pac;
+    IndexView v;
+};
+
+extern "C" {
+
+void *hs_index_new(const uint8_t *bwt_syms, uint64_t n, uint64_t primary, const uint64_t *sa_samples, uint64_t n_sa,
+                   int sa_intv, const uint8_t *pac, uint64_t l_pac)
+{
+    SimIndex *s = new SimIndex();
+    uint32_t nb = (uint32_t)(n / PS_BLK_SYMS + 1), cnt[4] = {0, 0, 0, 0};
+    s->blocks.resize(nb);
+    for (uint32_t b = 0; b < nb; ++b) {
+        uint64_t beg = (uint64_t)b * PS_BLK_SYMS, m = beg < n ? (n - beg < PS_BLK_SYMS ? n - beg : PS_BLK_SYMS) : 0;
+        blk_pack(s->blocks[b], bwt_syms + (beg < n ? beg : 0), (int)m, cnt);
+        for (uint64_t t = 0; t < m; ++t) ++cnt[bwt_syms[beg + t]];
+    }
+    s->sa.resize(n_sa);
+    for (uint64_t i = 0; i < n_sa; ++i) s->sa[i] = (bwtint)sa_samples[i];
+    s->pac.assign(pac, pac + l_pac / 4 + 1);
+    IndexView &v = s->v;
+    v.blocks = s->blocks.data(); v.sa = s->sa.data(); v.pac = s->pac.data();
+    v.seq_len = (bwtint)n; v.primary = (bwtint)primary; v.l_pac = (bwtint)l_pac;
+    v.L2[0] = 0; for (int c = 0; c < 4; ++c) v.L2[c + 1] = v.L2[c] + cnt[c];
+    v.n_blocks = nb; v.n_sa = (uint32_t)n_sa; v.sa_intv = sa_intv;
+    return s;
+}
+void hs_index_free(void *p) { delete (SimIndex *)p; }
+
+uint32_t hs_occ(void *p, int64_t k, int c) // Occ(k,c) through the block code, k in [-1, n]
+{
+    SimIndex *s = (SimIndex *)p; LaneStats st; memset(&st, 0, sizeof st);
+    uint32_t ok, ol;
+    // occ_pair1 returns Occ(k'-1) and Occ(l): ask for k' = k+1
+    occ_pair1(s->v, (bwtint)(k + 1), (bwtint)(k < 0 ? 0 : k), c, ok, ol, st);
+    return ok;
+}
+uint32_t hs_sa(void *p, uint64_t row)
+{
+    SimIndex *s = (SimIndex *)p; LaneStats st; memset(&st, 0, sizeof st);
+    bwtint r = (bwtint)row; uint32_t steps = 0;
+    while (sa_walk_step(s->v, r, steps, st)) {}
+    return steps + s->v.sa[r / s->v.sa_intv];
+}
+
+// Width stage + backtracking stage for n_reads reads of one length, simulated with n_lanes lanes.
+// codes: [n_reads][len] (0..3, 4 = N).  Outputs: w_out [len+1][n_reads] (pre-shadow), cwb, alns.
+int hs_aln(void *p, const Model *md, int n_reads, int len, const uint8_t *codes, int n_lanes, int pool_cap, int aln_cap,
+           uint32_t *w_out, uint8_t *cwb_out, uint8_t *cswb_out, AlnRec *alns, int32_t *n_aln, uint8_t *status, KStats *ks)
+{
+    SimIndex *s = (SimIndex *)p;
+    int n_bw = (len + 15) / 16, n_mw = (len + 31) / 32;
+    std::vector<uint32_t> bases((size_t)n_bw * n_reads, 0), nmask((size_t)n_mw * n_reads, 0);
+    for (int r = 0; r < n_reads; ++r)
+        for (int j = 0; j < len; ++j) {
+            int c = codes[(size_t)r * len + j];
+            if (c > 3) nmask[(size_t)(j >> 5) * n_reads + r] |= 1u << (j & 31);
+            else bases[(size_t)(j >> 4) * n_reads + r] |= (uint32_t)c << (2 * (j & 15));
+        }
+    int seed_len = md->seed_len;
+    std::vector<uint32_t> w((size_t)(len + 1) * n_reads);
+    std::vector<uint8_t> cwb((size_t)(len + 1) * n_reads), cswb((size_t)(seed_len + 1) * n_reads, 0);
+    LaneStats st; memset(&st, 0, sizeof st);
+    for (int r = 0; r < n_reads; ++r) {                 // width kernel body
+        WChain A, B; wchain_init(s->v, A); wchain_init(s->v, B);
+        for (int i = 0; i < len; ++i) {
+            uint32_t wv; uint8_t cb;
+            wchain_step(s->v, A, read_base(bases.data(), nmask.data(), n_reads, r, len - 1 - i), wv, cb, i == 0, st);
+            w[(size_t)i * n_reads + r] = wv; cwb[(size_t)i * n_reads + r] = cb;
+            if (md->use_seed && i < seed_len) {
+                wchain_step(s->v, B, read_base(bases.data(), nmask.data(), n_reads, r, seed_len - 1 - i), wv, cb, i == 0, st);
+                cswb[(size_t)i * n_reads + r] = cb;
+            }
+        }
+        w[(size_t)len * n_reads + r] = 0; cwb[(size_t)len * n_reads + r] = cw_pack(A.bid + 1, false);
+        if (md->use_seed) cswb[(size_t)seed_len * n_reads + r] = cw_pack(B.bid + 1, false);
+    }
+    if (w_out) memcpy(w_out, w.data(), w.size() * 4);
+    if (cwb_out) memcpy(cwb_out, cwb.data(), cwb.size());
+    if (cswb_out) memcpy(cswb_out, cswb.data(), cswb.size());
+    BtArgs a; memset(&a, 0, sizeof a);
+    a.ix = s->v; a.md = *md; a.n_reads = n_reads; a.len = len; a.n_lanes = n_lanes;
+    a.bases = bases.data(); a.nmask = nmask.data(); a.n_bw = n_bw; a.n_mw = n_mw;
+    a.w = w.data(); a.cwb = cwb.data(); a.cswb = cswb.data();
+    a.alns = alns; a.aln_cap = aln_cap; a.n_aln = n_aln; a.status = status;
+    std::vector<Entry> pool((size_t)n_lanes * pool_cap);
+    std::vector<uint32_t> heads((size_t)n_lanes * PS_MAX_BUCKETS);
+    a.pool = pool.data(); a.pool_cap = (uint32_t)pool_cap; a.heads = heads.data();
+    int lmb = lm_bytes(len, seed_len);
+    std::vector<uint8_t> lm((size_t)n_lanes * lmb);
+    std::vector<BtLane> lanes(n_lanes); std::vector<int> next(n_lanes);
+    for (int t = 0; t < n_lanes; ++t) { memset(&lanes[t], 0, sizeof(BtLane)); lanes[t].mode = M_FETCH; next[t] = t; }
+    bool any = true;
+    while (any) {                                        // lock-step over lanes, like a wave
+        any = false;
+        for (int t = 0; t < n_lanes; ++t) {
+            BtLane &L = lanes[t];
+            if (L.mode == M_EXIT) continue;
+            BtMem m; uint8_t *mine = lm.data() + (size_t)t * lmb;
+            m.cw = mine; m.csw = mine + len + 1; m.seq = m.csw + seed_len + 1;
+            m.pool = a.pool + (size_t)t * pool_cap; m.heads = a.heads + (size_t)t * PS_MAX_BUCKETS;
+            bt_iter(a, L, m, next[t], n_lanes);
+            any = true;
+        }
+    }
+    if (ks) {
+        memset(ks, 0, sizeof *ks);
+        for (int t = 0; t < n_lanes; ++t) {
+            ks->occ_pairs += lanes[t].st.pairs; ks->occ_same_blk += lanes[t].st.same; ks->nodes += lanes[t].st.nodes;
+            ks->pushes += lanes[t].st.pushes; ks->pops += lanes[t].st.pops; ks->iters += lanes[t].st.iters;
+            ks->exact_steps += lanes[t].st.exact;
+        }
+        ks->occ_pairs += st.pairs; ks->occ_same_blk += st.same;
+    }
+    return 0;
+}
+
+// banded global alignment of query codes against pac[rb, rb+tlen)
+int hs_banded(void *p, int qlen, const uint8_t *q, uint32_t rb, int tlen, int w, uint32_t *cigar, int cap)
+{
+    SimIndex *s = (SimIndex *)p;
+    std::vector<int32_t> H(qlen + 2), E(qlen + 2);
+    int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
+    std::vector<uint8_t> z((size_t)n_col * tlen + 1);
+    return banded_global(qlen, [&](int j) { return (int)q[j]; }, tlen, s->v.pac, rb, w, H.data(), E.data(), 1, z.data(), 1, cigar, cap);
+}
+
+int hs_model_stock(const char *n_arg, int len, Model *out)
+{
+    Options o; std::string err; set_stock_n(o, n_arg);
+    return make_model(o, len, *out, err) ? 0 : -1;
+}
+int hs_model_profile(const double *P, double ins, double del, int x, int len, Model *out)
+{
+    Options o; std::string err; profile_costs(o, P, ins, del, x);
+    return make_model(o, len, *out, err) ? 0 : -1;
+}
+size_t hs_sizeof_model(void) { return sizeof(Model); }
+size_t hs_sizeof_alnrec(void) { return sizeof(AlnRec); }
+}
