@@ -1,0 +1,97 @@
+/*
+ * parasuite_hip.h -- C ABI of libparasuite_hip.so, the MI355X (gfx950) replacement for the
+ * aligner child processes of PARA-suite's `map` command.
+ *
+ * Reference interfaces replaced (paths relative to /root/reference):
+ *   ps_index        <- exec `bwa index <ref>`                     src/src/mapping/PARAsuiteMapping.java:45-55,
+ *                                                                 src/src/mapping/BWAMapping.java:35-45
+ *   ps_map          <- exec `bwa parasuite -t T -X mm -p EP -g IP ref fq -f P.sai`
+ *                      + `bwa samse ref P.sai fq -f P.sam`        PARAsuiteMapping.java:63-77,84-92
+ *                      (error_profile == NULL: `bwa aln -t T -n mm` + samse,  BWAMapping.java:51-61,68-75)
+ *   ps_last_error   <- child exit status + inherited stderr       src/src/mapping/Mapping.java:151-198
+ * The Java method these sit behind is Mapping.executeMapping(int threads, String reference,
+ * String input, String outputPrefix, int mappingQualityFilter, String additionalOptions)
+ * (Mapping.java:40-42); INTEGRATION.md shows the JNI subclass and the argv-compatible `bwa` shim.
+ *
+ * Conventions: UTF-8 paths, int return 0 = success / non-zero = failure (message via
+ * ps_last_error() and on stderr), synchronous, one call at a time per process, never exit()s or
+ * throws across the boundary.  There is no CPU implementation: without a HIP device every
+ * computing entry point fails.
+ */
+#ifndef PARASUITE_HIP_H
+#define PARASUITE_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char *ps_version(void);
+const char *ps_last_error(void);
+
+/* `bwa index`: writes <ref_fa>.bwt/.sa/.pac/.ann (this project's formats; the caller only tests that
+ * <ref_fa>.bwt exists, PARAsuiteMapping.java:45-46).  Suffix sorting runs on the GPU. */
+int ps_index(const char *ref_fa);
+
+/* `bwa parasuite` (or `bwa aln` when error_profile is NULL) + `bwa samse` fused: FASTQ in, SAM out.
+ * threads: host worker threads for parsing/formatting (the reference's -t).  mm: the -X (profile
+ * mode) or -n (stock mode) argument as the Java passes it, e.g. "-1", "2", "0.04". */
+int ps_map(int threads, const char *mm, const char *error_profile, const char *indel_profile,
+           const char *ref_fa, const char *fastq, const char *out_sam);
+
+/* ---- staged interface (same code path as ps_map; used by the argv shim, tests and bench.py) ---- */
+typedef struct ps_ctx ps_ctx;
+typedef struct ps_batch ps_batch;
+
+ps_ctx *ps_ctx_open(const char *ref_fa, int device);                 /* load <ref_fa>.bwt ... into HBM  */
+ps_ctx *ps_ctx_build(const char *ref_fa, int device, int save_files);/* build the index (GPU), keep it resident */
+void    ps_ctx_close(ps_ctx *);
+int     ps_ctx_set_stock(ps_ctx *, const char *n_arg);               /* bwa aln -n */
+int     ps_ctx_set_profile(ps_ctx *, const char *error_profile, const char *indel_profile, const char *x_arg);
+int     ps_ctx_set_profile_matrix(ps_ctx *, const double P[16], double ins_rate, double del_rate, int x);
+int     ps_ctx_set_tiers(ps_ctx *, const uint32_t pool_cap[3], const int32_t aln_cap[3], int bt_blocks);
+
+typedef struct {                       /* index geometry + build facts */
+    uint64_t seq_len, l_pac, primary, L2[5], n_blocks, n_sa, device_bytes;
+    int32_t n_contigs, n_holes, sa_rounds, sa_intv;
+    double build_ms;
+} ps_index_info;
+int     ps_ctx_info(ps_ctx *, ps_index_info *out);
+/* index blobs (0 Occ blocks, 1 sampled SA, 2 pac) for the one-off RCCL broadcast over xGMI */
+int     ps_ctx_blob(ps_ctx *, int which, void **dev_ptr, uint64_t *bytes);
+int64_t ps_ctx_meta(ps_ctx *, char *buf, int64_t cap);               /* serialised contig/hole table + scalars */
+ps_ctx *ps_ctx_from_blobs(const char *meta, int64_t meta_len, int device, void *const dev_ptrs[3]); /* borrowed device memory */
+int     ps_ctx_fetch(ps_ctx *, int which, void *host_dst, uint64_t bytes); /* D2H copy of a blob (tests) */
+
+ps_batch *ps_batch_from_fastq(ps_ctx *, const char *fastq);
+ps_batch *ps_batch_from_codes(ps_ctx *, int64_t n, int len, const uint8_t *codes); /* [n][len], 0..3 ACGT, 4 N */
+void      ps_batch_free(ps_batch *);
+int64_t   ps_batch_n(ps_batch *);
+int       ps_batch_search(ps_batch *);                               /* width + backtracking kernels */
+int       ps_batch_select_hard(ps_batch *, uint64_t draws_before, uint64_t *draws_after);
+int       ps_batch_select_easy(ps_batch *, int threads);
+int       ps_batch_locate(ps_batch *);                               /* SA walk + MAPQ + banded DP kernels */
+int       ps_batch_run(ps_batch *, int threads);                     /* the four stages above, single process */
+int       ps_batch_write_sam(ps_batch *, const char *path, int with_header, int threads);
+
+typedef struct { uint32_t k, l; uint16_t score, units; uint8_t n_mm, n_gapo, n_gape, n_ins, n_del, pad[3]; } ps_aln;
+typedef struct {
+    int64_t pos; uint32_t sa; int32_t type, strand, mapq, n_mm, n_gapo, n_gape, ref_shift, score, c1, c2,
+            n_cigar, n_multi; uint32_t cigar[16];
+} ps_hit;
+typedef struct {
+    double ms_width, ms_backtrack, ms_compact, ms_select, ms_sa2pos, ms_refine, ms_host_post, ms_total;
+    int32_t n_width_launches, n_backtrack_launches;
+    int64_t n_overflow_tier1, n_overflow_tier2;
+} ps_timing;
+typedef struct { uint64_t occ_pairs, occ_same_blk, nodes, pushes, pops, lf_steps, iters, exact_steps; } ps_kstats;
+
+int     ps_batch_n_aln(ps_batch *, int32_t *out, int64_t cap);       /* per read, input order */
+int64_t ps_batch_alns(ps_batch *, int64_t read, ps_aln *out, int64_t cap);
+int     ps_batch_hits(ps_batch *, ps_hit *out, int64_t cap);
+int     ps_batch_timing(ps_batch *, ps_timing *out);
+int     ps_batch_kstats(ps_batch *, int which /*0 width 1 backtrack 2 sa2pos*/, ps_kstats *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

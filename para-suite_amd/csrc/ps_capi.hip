@@ -1,0 +1,262 @@
+// ps_capi.hip -- extern "C" boundary (include/parasuite_hip.h).  Exceptions stop here.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include "../../include/parasuite_hip.h"
+#include "ps_pipeline.h"
+
+using namespace ps;
+
+static thread_local std::string g_err;
+static int fail(const std::string &m) { g_err = m; std::fprintf(stderr, "[parasuite-hip] error: %s\n", m.c_str()); return 1; }
+#define PS_TRY try {
+#define PS_CATCH_INT } catch (const std::exception &e) { return fail(e.what()); } catch (...) { return fail("unknown error"); }
+#define PS_CATCH_PTR } catch (const std::exception &e) { fail(e.what()); return nullptr; } catch (...) { fail("unknown error"); return nullptr; }
+
+struct ps_ctx { Ctx c; };
+struct ps_batch { std::unique_ptr<Batch> b; };
+
+static_assert(sizeof(ps_aln) == sizeof(AlnRec), "ps_aln layout");
+
+extern "C" {
+
+const char *ps_version(void) { return "parasuite-hip 0.1 (gfx950)"; }
+const char *ps_last_error(void) { return g_err.c_str(); }
+
+static ps_ctx *new_ctx(int device)
+{
+    require_device(device);
+    ps_ctx *x = new ps_ctx();
+    x->c.device = device;
+    PS_HIP(hipStreamCreateWithFlags(&x->c.stream, hipStreamNonBlocking));
+    return x;
+}
+
+ps_ctx *ps_ctx_open(const char *ref_fa, int device)
+{
+    ps_ctx *x = nullptr;
+    PS_TRY
+        x = new_ctx(device);
+        index_load(ref_fa, x->c.ix, x->c.stream);
+        return x;
+    } catch (const std::exception &e) { delete x; fail(e.what()); return nullptr; } catch (...) { delete x; fail("unknown error"); return nullptr; }
+}
+ps_ctx *ps_ctx_build(const char *ref_fa, int device, int save_files)
+{
+    ps_ctx *x = nullptr;
+    PS_TRY
+        x = new_ctx(device);
+        index_build(ref_fa, x->c.ix, x->c.stream);
+        if (save_files) index_save(x->c.ix, ref_fa);
+        return x;
+    } catch (const std::exception &e) { delete x; fail(e.what()); return nullptr; } catch (...) { delete x; fail("unknown error"); return nullptr; }
+}
+void ps_ctx_close(ps_ctx *x) { delete x; }
+
+int ps_index(const char *ref_fa)
+{
+    PS_TRY
+        ps_ctx *x = ps_ctx_build(ref_fa, 0, 1);
+        if (!x) return 1;
+        delete x;
+        return 0;
+    PS_CATCH_INT
+}
+
+int ps_ctx_set_stock(ps_ctx *x, const char *n_arg)
+{
+    PS_TRY
+        Options o; set_stock_n(o, n_arg);
+        if (o.max_diff < 0 && !(o.fnr > 0.0)) throw Error("bad -n argument");
+        x->c.opt = o; return 0;
+    PS_CATCH_INT
+}
+int ps_ctx_set_profile_matrix(ps_ctx *x, const double P[16], double ins, double del, int xarg)
+{
+    PS_TRY
+        Options o; profile_costs(o, P, ins, del, xarg); x->c.opt = o; return 0;
+    PS_CATCH_INT
+}
+int ps_ctx_set_profile(ps_ctx *x, const char *ep, const char *ip, const char *x_arg)
+{
+    PS_TRY
+        double P[16], ins, del; std::string err;
+        if (!read_profile_files(ep, ip, P, ins, del, err)) throw Error(err);
+        return ps_ctx_set_profile_matrix(x, P, ins, del, x_arg ? std::atoi(x_arg) : -1);
+    PS_CATCH_INT
+}
+int ps_ctx_set_tiers(ps_ctx *x, const uint32_t pool_cap[3], const int32_t aln_cap[3], int bt_blocks)
+{
+    PS_TRY
+        for (int t = 0; t < 3; ++t) { if (pool_cap) x->c.pool_cap[t] = pool_cap[t]; if (aln_cap) x->c.aln_cap[t] = aln_cap[t]; }
+        x->c.bt_blocks = bt_blocks; return 0;
+    PS_CATCH_INT
+}
+int ps_ctx_info(ps_ctx *x, ps_index_info *o)
+{
+    PS_TRY
+        const Index &ix = x->c.ix;
+        o->seq_len = ix.view.seq_len; o->l_pac = ix.view.l_pac; o->primary = ix.view.primary;
+        for (int j = 0; j < 5; ++j) o->L2[j] = ix.view.L2[j];
+        o->n_blocks = ix.view.n_blocks; o->n_sa = ix.view.n_sa; o->device_bytes = ix.device_bytes();
+        o->n_contigs = (int)ix.ref.contigs.size(); o->n_holes = (int)ix.ref.holes.size(); o->sa_rounds = ix.sa_rounds; o->sa_intv = ix.view.sa_intv;
+        o->build_ms = ix.build_ms; return 0;
+    PS_CATCH_INT
+}
+int ps_ctx_blob(ps_ctx *x, int which, void **p, uint64_t *bytes)
+{
+    PS_TRY
+        Index &ix = x->c.ix;
+        if (which == 0) { *p = ix.blocks.p; *bytes = ix.blocks.n * sizeof(OccBlock); }
+        else if (which == 1) { *p = ix.sa.p; *bytes = ix.sa.n * sizeof(bwtint); }
+        else if (which == 2) { *p = ix.pac.p; *bytes = ix.pac.n; }
+        else throw Error("blob index out of range");
+        return 0;
+    PS_CATCH_INT
+}
+int64_t ps_ctx_meta(ps_ctx *x, char *buf, int64_t cap)
+{
+    try {
+        std::string m = index_meta_serialize(x->c.ix);
+        if (buf && cap >= (int64_t)m.size()) std::memcpy(buf, m.data(), m.size());
+        return (int64_t)m.size();
+    } catch (const std::exception &e) { fail(e.what()); return -1; }
+}
+ps_ctx *ps_ctx_from_blobs(const char *meta, int64_t meta_len, int device, void *const ptrs[3])
+{
+    ps_ctx *x = nullptr;
+    PS_TRY
+        x = new_ctx(device);
+        Index &ix = x->c.ix;
+        index_meta_deserialize(std::string(meta, (size_t)meta_len), ix);
+        const bwtint primary = ix.view.primary; bwtint L2[5]; std::memcpy(L2, ix.view.L2, sizeof L2);
+        const size_t nb = ix.view.n_blocks, ns = ix.view.n_sa, np = (size_t)ix.ref.l_pac / 4 + 1;
+        ix.blocks.adopt((OccBlock *)ptrs[0], nb); ix.sa.adopt((bwtint *)ptrs[1], ns); ix.pac.adopt((uint8_t *)ptrs[2], np);
+        ix.ref.pac.resize(np);
+        PS_HIP(hipMemcpy(ix.ref.pac.data(), ix.pac.p, np, hipMemcpyDeviceToHost));
+        ix.refresh_view();
+        ix.view.primary = primary; std::memcpy(ix.view.L2, L2, sizeof L2);
+        return x;
+    } catch (const std::exception &e) { delete x; fail(e.what()); return nullptr; } catch (...) { delete x; fail("unknown error"); return nullptr; }
+}
+int ps_ctx_fetch(ps_ctx *x, int which, void *dst, uint64_t bytes)
+{
+    PS_TRY
+        void *p; uint64_t n;
+        if (ps_ctx_blob(x, which, &p, &n)) return 1;
+        if (bytes > n) throw Error("fetch larger than blob");
+        PS_HIP(hipMemcpy(dst, p, bytes, hipMemcpyDeviceToHost));
+        return 0;
+    PS_CATCH_INT
+}
+
+ps_batch *ps_batch_from_fastq(ps_ctx *x, const char *fastq)
+{
+    PS_TRY
+        require_device(x->c.device);
+        ReadSet rs; load_reads(fastq, rs);
+        ps_batch *b = new ps_batch();
+        b->b = batch_create(&x->c, std::move(rs));
+        return b;
+    PS_CATCH_PTR
+}
+ps_batch *ps_batch_from_codes(ps_ctx *x, int64_t n, int len, const uint8_t *codes)
+{
+    PS_TRY
+        require_device(x->c.device);
+        ReadSet rs; reads_from_codes(n, len, codes, rs);
+        ps_batch *b = new ps_batch();
+        b->b = batch_create(&x->c, std::move(rs));
+        return b;
+    PS_CATCH_PTR
+}
+void ps_batch_free(ps_batch *b) { delete b; }
+int64_t ps_batch_n(ps_batch *b) { return b->b->rs.n; }
+int ps_batch_search(ps_batch *b) { PS_TRY batch_search(*b->b); return 0; PS_CATCH_INT }
+int ps_batch_select_hard(ps_batch *b, uint64_t before, uint64_t *after) { PS_TRY batch_select_hard(*b->b, before, after); return 0; PS_CATCH_INT }
+int ps_batch_select_easy(ps_batch *b, int threads) { PS_TRY batch_select_easy(*b->b, threads); return 0; PS_CATCH_INT }
+int ps_batch_locate(ps_batch *b) { PS_TRY batch_locate(*b->b); return 0; PS_CATCH_INT }
+int ps_batch_run(ps_batch *b, int threads)
+{
+    PS_TRY
+        batch_search(*b->b);
+        batch_select_hard(*b->b, 0, nullptr);
+        batch_select_easy(*b->b, threads);
+        batch_locate(*b->b);
+        return 0;
+    PS_CATCH_INT
+}
+int ps_batch_write_sam(ps_batch *b, const char *path, int with_header, int threads)
+{
+    PS_TRY
+        batch_write_sam(*b->b, path, with_header != 0, "@PG\tID:parasuite-hip\tPN:parasuite-hip\tVN:0.1", threads); return 0;
+    PS_CATCH_INT
+}
+int ps_batch_n_aln(ps_batch *b, int32_t *out, int64_t cap)
+{
+    PS_TRY
+        Batch &B = *b->b;
+        for (int64_t g = 0; g < B.rs.n && g < cap; ++g) { int n; B.alns_of(g, n); out[g] = n; }
+        return 0;
+    PS_CATCH_INT
+}
+int64_t ps_batch_alns(ps_batch *b, int64_t read, ps_aln *out, int64_t cap)
+{
+    try {
+        int n; const AlnRec *a = b->b->alns_of(read, n);
+        for (int j = 0; j < n && j < cap; ++j) std::memcpy(&out[j], &a[j], sizeof(ps_aln));
+        return n;
+    } catch (const std::exception &e) { fail(e.what()); return -1; }
+}
+int ps_batch_hits(ps_batch *b, ps_hit *out, int64_t cap)
+{
+    PS_TRY
+        Batch &B = *b->b;
+        for (int64_t g = 0; g < B.rs.n && g < cap; ++g) {
+            const Hit &h = B.hits[g]; ps_hit &o = out[g];
+            o.pos = h.type ? h.pos : -1; o.sa = h.sa; o.type = h.type; o.strand = h.strand; o.mapq = h.mapq; o.n_mm = h.n_mm; o.n_gapo = h.n_gapo;
+            o.n_gape = h.n_gape; o.ref_shift = h.ref_shift; o.score = h.score; o.c1 = h.c1; o.c2 = h.c2; o.n_cigar = h.n_cigar; o.n_multi = h.n_multi;
+            std::memcpy(o.cigar, h.cigar, sizeof o.cigar);
+        }
+        return 0;
+    PS_CATCH_INT
+}
+int ps_batch_timing(ps_batch *b, ps_timing *o)
+{
+    PS_TRY
+        const Timing &t = b->b->tm;
+        o->ms_width = t.ms_width; o->ms_backtrack = t.ms_backtrack; o->ms_compact = t.ms_compact; o->ms_select = t.ms_select;
+        o->ms_sa2pos = t.ms_sa2pos; o->ms_refine = t.ms_refine; o->ms_host_post = t.ms_host_post; o->ms_total = t.ms_total;
+        o->n_width_launches = t.n_width_launches; o->n_backtrack_launches = t.n_backtrack_launches;
+        o->n_overflow_tier1 = b->b->n_overflow[1]; o->n_overflow_tier2 = b->b->n_overflow[2];
+        return 0;
+    PS_CATCH_INT
+}
+int ps_batch_kstats(ps_batch *b, int which, ps_kstats *o)
+{
+    PS_TRY
+        const KStats &k = which == 0 ? b->b->st_width : (which == 1 ? b->b->st_backtrack : b->b->st_sa2pos);
+        o->occ_pairs = k.occ_pairs; o->occ_same_blk = k.occ_same_blk; o->nodes = k.nodes; o->pushes = k.pushes; o->pops = k.pops;
+        o->lf_steps = k.lf_steps; o->iters = k.iters; o->exact_steps = k.exact_steps; return 0;
+    PS_CATCH_INT
+}
+
+int ps_map(int threads, const char *mm, const char *error_profile, const char *indel_profile,
+           const char *ref_fa, const char *fastq, const char *out_sam)
+{
+    PS_TRY
+        ps_ctx *x = index_files_exist(ref_fa) ? ps_ctx_open(ref_fa, 0) : ps_ctx_build(ref_fa, 0, 1);
+        if (!x) return 1;
+        int rc = error_profile && error_profile[0] ? ps_ctx_set_profile(x, error_profile, indel_profile, mm)
+                                                   : ps_ctx_set_stock(x, mm && mm[0] ? mm : "0.04");
+        ps_batch *b = rc ? nullptr : ps_batch_from_fastq(x, fastq);
+        if (!rc && !b) rc = 1;
+        if (!rc) rc = ps_batch_run(b, threads);
+        if (!rc) rc = ps_batch_write_sam(b, out_sam, 1, threads);
+        ps_batch_free(b); ps_ctx_close(x);
+        return rc;
+    PS_CATCH_INT
+}
+
+}  // extern "C"

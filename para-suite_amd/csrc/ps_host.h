@@ -1,0 +1,76 @@
+// ps_host.h -- internal host-side interface of libparasuite_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "ps_types.h"
+#include "ps_model.h"
+#include "ps_kernels.h"
+
+namespace ps {
+
+struct Error : std::runtime_error { using std::runtime_error::runtime_error; };
+
+#define PS_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) \
+    throw ps::Error(std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+
+// The product has no CPU path: every entry point that computes calls this first.
+void require_device(int device);
+
+template <class T> struct DevBuf {
+    T *p = nullptr; size_t n = 0; bool owned = true;
+    DevBuf() {}
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n), owned(o.owned) { o.p = nullptr; o.n = 0; }
+    DevBuf &operator=(DevBuf &&o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; owned = o.owned; o.p = nullptr; o.n = 0; } return *this; }
+    ~DevBuf() { release(); }
+    void release() { if (p && owned) (void)hipFree(p); p = nullptr; n = 0; owned = true; }
+    void alloc(size_t count) { release(); n = count; if (count) PS_HIP(hipMalloc((void **)&p, count * sizeof(T))); }
+    void adopt(T *ptr, size_t count) { release(); p = ptr; n = count; owned = false; }
+    void zero(hipStream_t s = 0) { if (n) PS_HIP(hipMemsetAsync(p, 0, n * sizeof(T), s)); }
+    void upload(const T *src, size_t count, hipStream_t s = 0) { PS_HIP(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, s)); }
+    void download(T *dst, size_t count, hipStream_t s = 0) const { PS_HIP(hipMemcpyAsync(dst, p, count * sizeof(T), hipMemcpyDeviceToHost, s)); }
+};
+
+// ---- reference sequence metadata (what upstream keeps in .ann/.amb/.pac) ----
+struct Contig { std::string name, anno; int64_t offset; int32_t len; int32_t n_ambs; };
+struct Hole { int64_t offset; int32_t len; char amb; };
+struct RefSeq {
+    std::vector<Contig> contigs; std::vector<Hole> holes;
+    std::vector<uint8_t> pac;   // forward strand, 2 bit
+    int64_t l_pac = 0;
+    int pos2rid(int64_t pos_f) const;
+    int cnt_ambi(int64_t pos_f, int len, int *ref_id) const;
+};
+void load_fasta(const char *path, RefSeq &ref);
+
+// 48-bit LCG of POSIX drand48/lrand48 (the generator upstream bwa seeds with 11)
+struct Rng48 {
+    uint64_t x;
+    explicit Rng48(long seed = 11) { x = (((uint64_t)(uint32_t)seed) << 16) | 0x330E; }
+    uint64_t step() { x = (x * 0x5DEECE66DULL + 0xBULL) & 0xFFFFFFFFFFFFULL; return x; }
+    double drand() { return (double)step() * (1.0 / 281474976710656.0); }
+    long lrand() { return (long)(step() >> 17); }
+    void jump(uint64_t t);      // advance by t draws in O(log t)
+};
+
+struct Index {
+    RefSeq ref;
+    DevBuf<OccBlock> blocks; DevBuf<bwtint> sa; DevBuf<uint8_t> pac;
+    IndexView view;
+    double build_ms = 0;
+    int sa_rounds = 0;
+    void refresh_view();
+    size_t device_bytes() const { return blocks.n * sizeof(OccBlock) + sa.n * sizeof(bwtint) + pac.n; }
+};
+void index_build(const char *fa, Index &ix, hipStream_t s);        // GPU suffix sorting (ps_index.hip)
+void index_save(const Index &ix, const std::string &prefix);
+void index_load(const std::string &prefix, Index &ix, hipStream_t s);
+bool index_files_exist(const std::string &prefix);
+std::string index_meta_serialize(const Index &ix);
+void index_meta_deserialize(const std::string &blob, Index &ix);   // fills ref + view scalars, no device data
+
+}  // namespace ps

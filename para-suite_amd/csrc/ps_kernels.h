@@ -1,0 +1,33 @@
+// ps_kernels.h -- launch interface of the gfx950 kernels (ps_kernels.hip, ps_index.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "ps_types.h"
+
+namespace ps {
+
+static const int PS_MAX_CIGAR = 16;
+
+struct WidthArgs {
+    IndexView ix;
+    int n_reads, len, seed_len, use_seed;
+    const uint32_t *bases; const uint32_t *nmask;
+    uint32_t *w; uint8_t *cwb; uint8_t *cswb;
+    KStats *stats;
+};
+
+struct RefineItem { int32_t read; bwtint rb; int32_t ref_shift; int32_t strand; };
+struct RefineArgs {
+    IndexView ix;
+    int n_items, len, n_reads;
+    const uint32_t *bases; const uint32_t *nmask;
+    const RefineItem *items;
+    uint32_t *cigar; int32_t *n_cigar;     // [n_items][PS_MAX_CIGAR]
+    uint8_t *zbuf; size_t z_per_block;     // traceback scratch, 64 lanes interleaved per block
+};
+
+void launch_width(const WidthArgs &a, hipStream_t s);
+void launch_backtrack(const BtArgs &a, int n_blocks, int lm_stride, hipStream_t s);
+void launch_sa2pos(const IndexView &ix, const bwtint *rows, bwtint *out, int n, KStats *stats, hipStream_t s);
+void launch_refine(const RefineArgs &a, int n_blocks, hipStream_t s);
+
+}  // namespace ps

@@ -1,0 +1,159 @@
+// ps_kernels.hip -- gfx950 kernels of the mapping hot path.
+//
+// Replaces the compute inside the `bwa aln|parasuite` and `bwa samse` child
+// processes of /root/reference/src/src/mapping/PARAsuiteMapping.java:63-92.
+// All four kernels are integer/lookup bound (no MFMA): one read (or one SA
+// row) per lane, 64-byte Occ blocks fetched as four 16-byte loads, per-lane
+// search state in LDS, loops flattened so that every lane of a wave issues its
+// random HBM load in the same iteration.
+#include <hip/hip_runtime.h>
+#include "ps_core.h"
+#include "ps_kernels.h"
+
+namespace ps {
+
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ void flush_stats(KStats *ks, const LaneStats &st)
+{
+    if (!ks) return;
+    unsigned long long v[8] = {st.pairs, st.same, st.nodes, st.pushes, st.pops, st.lf, st.iters, st.exact};
+    unsigned long long *dst = reinterpret_cast<unsigned long long *>(ks);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        unsigned long long s = wave_sum(v[j]);
+        if ((threadIdx.x & 63) == 0 && s) atomicAdd(dst + j, s);
+    }
+}
+
+// ---- width stage: D(i) bounds for the read and for its seed ---------------
+__global__ void __launch_bounds__(256) k_width(WidthArgs a)
+{
+    const int stride = gridDim.x * blockDim.x;
+    LaneStats st = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < a.n_reads; r += stride) {
+        WChain A, B;
+        wchain_init(a.ix, A); wchain_init(a.ix, B);
+        const int len = a.len, seed_len = a.seed_len;
+        uint32_t bw = 0, mw = 0, sbw = 0, smw = 0;  // current base / N-mask words of the two chains
+        for (int i = 0; i < len; ++i) {
+            int j = len - 1 - i;
+            if (i == 0 || (j & 15) == 15) bw = a.bases[(size_t)(j >> 4) * a.n_reads + r];
+            if (i == 0 || (j & 31) == 31) mw = a.nmask[(size_t)(j >> 5) * a.n_reads + r];
+            int base = ((mw >> (j & 31)) & 1u) ? 4 : (int)((bw >> (2 * (j & 15))) & 3u);
+            uint32_t wv; uint8_t cb;
+            if (a.use_seed && i < seed_len) {
+                int js = seed_len - 1 - i;
+                if (i == 0 || (js & 15) == 15) sbw = a.bases[(size_t)(js >> 4) * a.n_reads + r];
+                if (i == 0 || (js & 31) == 31) smw = a.nmask[(size_t)(js >> 5) * a.n_reads + r];
+                int sbase = ((smw >> (js & 31)) & 1u) ? 4 : (int)((sbw >> (2 * (js & 15))) & 3u);
+                uint32_t swv; uint8_t scb;
+                wchain_step(a.ix, B, sbase, swv, scb, i == 0, st);
+                a.cswb[(size_t)i * a.n_reads + r] = scb;
+            }
+            wchain_step(a.ix, A, base, wv, cb, i == 0, st);
+            a.w[(size_t)i * a.n_reads + r] = wv;
+            a.cwb[(size_t)i * a.n_reads + r] = cb;
+        }
+        a.w[(size_t)len * a.n_reads + r] = 0;
+        a.cwb[(size_t)len * a.n_reads + r] = cw_pack(A.bid + 1, false);
+        if (a.use_seed) a.cswb[(size_t)seed_len * a.n_reads + r] = cw_pack(B.bid + 1, false);
+    }
+    flush_stats(a.stats, st);
+}
+
+// ---- seed / backtracking stage --------------------------------------------
+__global__ void __launch_bounds__(256) k_backtrack(BtArgs a, int lm_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int lane_g = blockIdx.x * blockDim.x + threadIdx.x;
+    BtMem m;
+    uint8_t *mine = smem + (size_t)threadIdx.x * lm_stride;
+    m.cw = mine; m.csw = mine + a.len + 1; m.seq = m.csw + a.md.seed_len + 1;
+    m.pool = a.pool + (size_t)lane_g * a.pool_cap;
+    m.heads = a.heads + (size_t)lane_g * PS_MAX_BUCKETS;
+    BtLane L;
+    L.mode = M_FETCH; L.r = 0; L.have_cur = false; L.n_stack = 0; L.status = RS_OK; L.n_aln = 0;
+    L.st = {0, 0, 0, 0, 0, 0, 0, 0};
+    int next_r = lane_g;
+    while (L.mode != M_EXIT) bt_iter(a, L, m, next_r, a.n_lanes);
+    flush_stats(a.stats, L.st);
+}
+
+// ---- SA row -> text position ----------------------------------------------
+__global__ void __launch_bounds__(256) k_sa2pos(IndexView ix, const bwtint *rows, bwtint *out, int n, KStats *stats)
+{
+    const int stride = gridDim.x * blockDim.x;
+    int item = blockIdx.x * blockDim.x + threadIdx.x;
+    LaneStats st = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool have = false; bwtint row = 0; uint32_t steps = 0;
+    while (true) {
+        if (!have) {
+            if (item >= n) break;
+            row = rows[item]; steps = 0; have = true;
+        }
+        if (!sa_walk_step(ix, row, steps, st)) {
+            out[item] = steps + ix.sa[row / (bwtint)ix.sa_intv];
+            item += stride; have = false;
+        }
+    }
+    flush_stats(stats, st);
+}
+
+// ---- banded global alignment of gapped hits ---------------------------------
+// One hit per lane, 64 lanes per block; H/E rows in LDS ([j][lane]), traceback bytes in global memory.
+__global__ void __launch_bounds__(64) k_refine(RefineArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    int32_t *H = reinterpret_cast<int32_t *>(smem) + threadIdx.x;
+    int32_t *E = H + (size_t)(a.len + 2) * 64;
+    uint8_t *z = a.zbuf + (size_t)blockIdx.x * a.z_per_block + threadIdx.x;
+    for (int it = blockIdx.x * 64 + threadIdx.x; it < a.n_items; it += gridDim.x * 64) {
+        RefineItem q = a.items[it];
+        int tlen = a.len + q.ref_shift;
+        int d = tlen - a.len; if (d < 0) d = -d;
+        int w = (int)(d * 1.5); if (w < 50) w = 50;
+        const int r = q.read, len = a.len, n_reads = a.n_reads;
+        const uint32_t *bases = a.bases, *nmask = a.nmask;
+        const int strand = q.strand;
+        uint32_t cig[PS_MAX_CIGAR];
+        int n = banded_global(len,
+            [&](int j) { int b = read_base(bases, nmask, n_reads, r, strand ? len - 1 - j : j); return b > 3 ? 4 : (strand ? 3 - b : b); },
+            tlen, a.ix.pac, q.rb, w, H, E, 64, z, 64, cig, PS_MAX_CIGAR);
+        a.n_cigar[it] = n;
+        for (int j = 0; j < PS_MAX_CIGAR; ++j) a.cigar[(size_t)it * PS_MAX_CIGAR + j] = j < n ? cig[j] : 0;
+    }
+}
+
+// ---- launch wrappers ---------------------------------------------------------
+void launch_width(const WidthArgs &a, hipStream_t s)
+{
+    int blocks = (a.n_reads + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_width, dim3(blocks), dim3(256), 0, s, a);
+}
+void launch_backtrack(const BtArgs &a, int n_blocks, int lm_stride, hipStream_t s)
+{
+    const size_t lds = (size_t)256 * lm_stride;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_backtrack), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_backtrack, dim3(n_blocks), dim3(256), lds, s, a, lm_stride);
+}
+void launch_sa2pos(const IndexView &ix, const bwtint *rows, bwtint *out, int n, KStats *stats, hipStream_t s)
+{
+    int blocks = (n + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_sa2pos, dim3(blocks), dim3(256), 0, s, ix, rows, out, n, stats);
+}
+void launch_refine(const RefineArgs &a, int n_blocks, hipStream_t s)
+{
+    size_t lds = (size_t)(a.len + 2) * 64 * 4 * 2;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_refine), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_refine, dim3(n_blocks), dim3(64), lds, s, a);
+}
+
+}  // namespace ps

@@ -1,0 +1,81 @@
+// ps_pipeline.h -- batch pipeline behind the C ABI (host orchestration of the gfx950 kernels).
+#pragma once
+#include <map>
+#include <memory>
+#include "ps_host.h"
+
+namespace ps {
+
+struct ReadSet {
+    int64_t n = 0;
+    std::vector<int32_t> len;
+    std::vector<int64_t> off;        // n+1 offsets into seq / qual
+    std::vector<uint8_t> seq;        // codes 0..3, 4 = N, read orientation
+    std::vector<char> qual; bool has_qual = false;
+    std::vector<char> names; std::vector<int64_t> name_off;  // n+1
+    const char *name(int64_t i, size_t &l) const { l = (size_t)(name_off[i + 1] - name_off[i]); return names.data() + name_off[i]; }
+};
+void load_reads(const char *path, ReadSet &rs);               // FASTQ or FASTA
+void reads_from_codes(int64_t n, int len, const uint8_t *codes, ReadSet &rs);
+
+struct Multi { int64_t pos; bwtint row; int32_t gap, mm, ref_shift, strand, n_cigar; uint32_t cigar[PS_MAX_CIGAR]; };
+struct Hit {
+    int64_t pos; bwtint sa;
+    int32_t type, strand, mapq, n_mm, n_gapo, n_gape, ref_shift, score, c1, c2, n_cigar;
+    int32_t multi_begin, n_multi;
+    uint32_t cigar[PS_MAX_CIGAR];
+};
+
+struct Timing {
+    double ms_width = 0, ms_backtrack = 0, ms_compact = 0, ms_select = 0, ms_sa2pos = 0, ms_refine = 0, ms_host_post = 0, ms_total = 0;
+    int n_width_launches = 0, n_backtrack_launches = 0;
+};
+
+struct Ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    Index ix;
+    Options opt;
+    int bt_blocks = 0;             // grid of the backtracking kernel (0 = 4 blocks per CU)
+    uint32_t pool_cap[3] = {1024, 32768, 2000064};
+    int aln_cap[3] = {8, 256, 65536};
+    ~Ctx();
+};
+
+struct Bin {
+    int len = 0; Model md;
+    std::vector<int32_t> ids;                 // global read index of every local read
+    DevBuf<uint32_t> bases, nmask, w; DevBuf<uint8_t> cwb, cswb, status; DevBuf<AlnRec> alns; DevBuf<int32_t> n_aln;
+    std::vector<uint32_t> h_bases, h_nmask;   // host copy (tier re-runs gather from it)
+    std::vector<int32_t> h_n_aln; std::vector<uint32_t> h_off; std::vector<AlnRec> h_alns;   // compact hit lists
+    std::map<int32_t, std::vector<AlnRec>> overflow;                                          // reads that needed a larger tier
+    int n_bw = 0, n_mw = 0;
+};
+
+struct Batch {
+    Ctx *ctx = nullptr;
+    ReadSet rs;
+    std::vector<Bin> bins;
+    std::vector<int32_t> read_bin, read_local;
+    std::vector<Hit> hits; std::vector<Multi> multis;
+    // RNG bookkeeping for the tie-break stream (one sequential drand48 stream over reads)
+    std::vector<uint8_t> n_best;           // leading hits with the best score (saturated at 255)
+    std::vector<int64_t> hard;             // global indices of reads with >= 2 best hits
+    std::vector<uint64_t> hard_draws_cum;  // draws consumed by hard reads up to and including this one
+    std::vector<int64_t> easy_before;      // per hard read: mapped single-best reads before it
+    int64_t n_easy = 0; uint64_t draws_in = 0, draws_out = 0;
+    DevBuf<KStats> d_stats; KStats st_width{}, st_backtrack{}, st_sa2pos{};
+    Timing tm;
+    int64_t n_overflow[3] = {0, 0, 0};
+    bool searched = false, selected_hard = false, selected = false, located = false;
+    const AlnRec *alns_of(int64_t g, int &n) const;
+};
+
+std::unique_ptr<Batch> batch_create(Ctx *ctx, ReadSet &&rs);   // bins by length, packs 2-bit, uploads
+void batch_search(Batch &b);                                    // width + backtracking kernels (+ larger tiers), hit lists to host
+void batch_select_hard(Batch &b, uint64_t draws_before, uint64_t *draws_after);
+void batch_select_easy(Batch &b, int threads);
+void batch_locate(Batch &b);                                    // SA walk kernel, strand / MAPQ, banded DP of gapped hits
+void batch_write_sam(Batch &b, const char *path, bool header, const char *pg_line, int threads);
+
+}  // namespace ps

@@ -1,0 +1,147 @@
+"""GPU parity: libparasuite_hip.so (through its C ABI) against the CPU oracle, bit for bit.
+
+The oracle's status is PARITY UNPINNED (oracle/ps_oracle.h): the reference tree holds no aligner
+source, tests or golden SAM, so "identical to the reference" here means identical to this
+repository's restatement of BWA-0.7.8-style aln+samse semantics.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import sam_records, sam_sq
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx_example(example):
+    import capi
+    return capi.Ctx.build(example["fa"])
+
+
+@pytest.fixture(scope="module")
+def ctx_multi(multi):
+    import capi
+    return capi.Ctx.build(multi["fa"])
+
+
+def _check_index(ctx, oix):
+    info = ctx.info()
+    assert info.seq_len == oix.seq_len and info.l_pac == oix.l_pac
+    assert info.primary == oix.primary
+    assert list(info.L2) == oix.L2
+    syms, cnts = ctx.bwt_syms()
+    ref = oix.bwt_syms()
+    assert np.array_equal(syms, ref)
+    # block counts = running symbol counts at every 192-symbol boundary
+    run = np.zeros(4, dtype=np.int64)
+    onehot = np.stack([(ref == c) for c in range(4)], axis=1).astype(np.int64)
+    pre = np.concatenate([np.zeros((1, 4), dtype=np.int64), np.cumsum(onehot, axis=0)])
+    idx = np.minimum(np.arange(cnts.shape[0], dtype=np.int64) * 192, ref.size)
+    assert np.array_equal(cnts.astype(np.int64), pre[idx])
+    sa = ctx.fetch(1).view("<u4")
+    osa = oix.sa_samples()
+    assert sa.size == osa.size
+    assert np.array_equal(sa.astype(np.uint64), osa & np.uint64(0xFFFFFFFF))
+    assert np.array_equal(ctx.fetch(2), oix.pac())
+
+
+def test_index_matches_oracle(ctx_example, example):
+    _check_index(ctx_example, example["orc_index"])
+
+
+def test_index_multi_contig(ctx_multi, multi):
+    _check_index(ctx_multi, multi["orc_index"])
+    assert ctx_multi.info().n_contigs == 3
+
+
+def _aln_tuple(a):
+    return (int(a["k"]), int(a["l"]), int(a["n_mm"]), int(a["n_gapo"]), int(a["n_gape"]), int(a["n_ins"]),
+            int(a["n_del"]), int(a["score"]))
+
+
+def _compare(ctx, oix, opt, fq, workdir, tag, n_check_alns=400):
+    import orc
+    b = ctx.batch_from_fastq(fq)
+    b.run(threads=4)
+    gsam = os.path.join(workdir, tag + ".gpu.sam")
+    osam = os.path.join(workdir, tag + ".orc.sam")
+    osai = os.path.join(workdir, tag + ".orc.sai")
+    b.write_sam(gsam)
+    oix.map_fastq(opt, fq, osam, sai_out=osai, n_threads=8)
+    sai = orc.read_sai(osai)
+    n_aln = b.n_aln()
+    assert n_aln.tolist() == [len(x) for x in sai], tag
+    for r in range(min(len(sai), n_check_alns)):
+        got = [_aln_tuple(a) for a in b.alns(r)]
+        exp = [(int(a["k"]), int(a["l"]), int(a["n_mm"]), int(a["n_gapo"]), int(a["n_gape"]), int(a["n_ins"]),
+                int(a["n_del"]), int(a["score"])) for a in sai[r]]
+        assert got == exp, (tag, r)
+    assert sam_sq(gsam) == sam_sq(osam)
+    g, o = sam_records(gsam), sam_records(osam)
+    assert len(g) == len(o)
+    bad = [i for i in range(len(g)) if g[i] != o[i]]
+    assert not bad, (tag, len(bad), g[bad[0]], o[bad[0]])
+    return b
+
+
+def _fastq(genome, workdir, name, **kw):
+    import simulate as S
+    sim = S.simulate_reads(genome, **kw)
+    fq = os.path.join(workdir, name + ".fq")
+    S.write_fastq(fq, sim)
+    return fq
+
+
+@pytest.mark.parametrize("n_arg", ["0.04", "2", "0"])
+def test_stock_sam_bit_exact(ctx_example, example, workdir, n_arg):
+    import orc
+    fq = _fastq(example["genome"], workdir, "stock50", n_reads=3000, read_len=50, seed=11, indel_scale=30, n_frac=0.002)
+    ctx_example.set_stock(n_arg)
+    _compare(ctx_example, example["orc_index"], orc.stock_opt(n_arg), fq, workdir, "stock_" + n_arg)
+
+
+@pytest.mark.parametrize("x", [-1, 2])
+def test_profile_sam_bit_exact(ctx_example, example, workdir, x):
+    import orc
+    import simulate as S
+    P = S.EXAMPLE_PROFILE.copy()
+    P[3, 1], P[3, 3] = 0.12, 0.87          # a PAR-CLIP like T->C rate
+    fq = _fastq(example["genome"], workdir, "prof50", n_reads=3000, read_len=50, seed=12, indel_scale=30)
+    ctx_example.set_profile(P, 2.1e-5, 5.9e-4, x)
+    _compare(ctx_example, example["orc_index"], orc.profile_opt(P, 2.1e-5, 5.9e-4, x), fq, workdir, "prof_%d" % x)
+
+
+def test_mixed_lengths_and_contig_edges(ctx_multi, multi, workdir):
+    """ragged input (36-75 bp, length-binned on the device), multi contig, repeats, N runs"""
+    import orc
+    fq = _fastq(multi["genome"], workdir, "mixed", n_reads=2500, read_len=75, min_len=36, seed=13, indel_scale=40,
+                n_frac=0.003)
+    ctx_multi.set_stock("0.04")
+    _compare(ctx_multi, multi["orc_index"], orc.stock_opt("0.04"), fq, workdir, "mixed")
+
+
+def test_small_tiers_escalate(ctx_example, example, workdir):
+    """tiny stack/hit capacities force the larger search tiers; results must not change"""
+    import orc
+    fq = _fastq(example["genome"], workdir, "tiers", n_reads=600, read_len=50, seed=14, indel_scale=30)
+    ctx_example.set_stock("0.04")
+    ctx_example.set_tiers(pool_cap=[48, 4096, 2000064], aln_cap=[1, 64, 65536], bt_blocks=2)
+    try:
+        b = _compare(ctx_example, example["orc_index"], orc.stock_opt("0.04"), fq, workdir, "tiers")
+        assert b.timing()["n_overflow_tier1"] > 0
+    finally:
+        ctx_example.set_tiers(pool_cap=[1024, 32768, 2000064], aln_cap=[8, 256, 65536], bt_blocks=0)
+
+
+def test_empty_and_degenerate_reads(ctx_example, example, workdir):
+    import orc
+    fq = os.path.join(workdir, "degenerate.fq")
+    with open(fq, "w") as f:
+        f.write("@allN\n" + "N" * 40 + "\n+\n" + "I" * 40 + "\n")
+        f.write("@polyA/1\n" + "A" * 50 + "\n+\n" + "I" * 50 + "\n")
+        f.write("@short\nACGTACGTACGTAC\n+\nIIIIIIIIIIIIII\n")
+        f.write("@one\nA\n+\nI\n")
+    ctx_example.set_stock("0.04")
+    _compare(ctx_example, example["orc_index"], orc.stock_opt("0.04"), fq, workdir, "degenerate")
