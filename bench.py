@@ -1,0 +1,349 @@
+#!/usr/bin/env python3
+"""bench.py -- reads/s of the mapping hot path on MI355X.
+
+One "step" = one pass of the hot path (width kernel -> backtracking kernel -> tie-break selection ->
+SA-walk kernel -> banded-DP kernel) over one batch of synthetic PAR-CLIP reads that is already
+packed and resident in HBM.  Workload at N=1: BASELINE.json configs[2] -- 10 M x 50 bp simulated
+PAR-CLIP reads, full difference-tolerant search + gapped extension -- against a synthetic genome at
+the largest scale the 32-bit round-1 index supports in the time budget (--genome-mbp, default 1000;
+hg19 itself is not on the box and its 6.27 G-symbol BWT needs the 40-bit index).
+N>1: one process per GPU, the FM index built on rank 0 and broadcast once with RCCL, every rank maps
+its own --reads reads (weak scaling, no data-path collective); the only exchange is one integer per
+rank that chains the tie-break RNG stream in input order.
+
+Launch:  python bench.py [--gpus 1] [--steps K] [--warmup W]
+         python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "para-suite_amd"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+AT = 0.295
+PROFILE = [[0.990, 0.004, 0.003, 0.003], [0.004, 0.990, 0.003, 0.003], [0.006, 0.010, 0.977, 0.007],
+           [0.005, 0.005, 0.003, 0.987]]
+SITE_FREQ = [0.66, 0.24, 0.08, 0.04]
+INS_RATE, DEL_RATE = 2.1e-5, 5.9e-4
+
+
+def gen_genome(torch, dev, total_bp, n_contigs, seed):
+    """uint8 codes (0..3, 4 = N) per contig on the device; same stream on every rank."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    per = total_bp // n_contigs
+    out = []
+    for c in range(n_contigs):
+        n = per if c < n_contigs - 1 else total_bp - per * (n_contigs - 1)
+        codes = torch.empty(n, dtype=torch.uint8, device=dev)
+        for a in range(0, n, 1 << 27):
+            b = min(n, a + (1 << 27))
+            u = torch.rand(b - a, generator=g, device=dev)
+            codes[a:b] = ((u >= AT).to(torch.uint8) + (u >= 0.5).to(torch.uint8) + (u >= 1.0 - AT).to(torch.uint8))
+        if n > 400000:
+            run = 20000
+            mid = int(n * 0.4)
+            codes[:run // 2] = 4
+            codes[mid:mid + run] = 4
+            codes[n - run // 2:] = 4
+        out.append(("chr%d" % (c + 1), codes))
+    return out
+
+
+def write_fasta(path, contigs, width=50):
+    lut = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    with open(path, "wb") as f:
+        for name, codes in contigs:
+            f.write(b">" + name.encode() + b"\n")
+            n = codes.numel()
+            for a in range(0, n, 50_000_000):
+                b = min(n, a + 50_000_000)
+                asc = lut[codes[a:b].cpu().numpy()]
+                full = asc.size // width * width
+                if full:
+                    body = np.empty((full // width, width + 1), dtype=np.uint8)
+                    body[:, :width] = asc[:full].reshape(-1, width)
+                    body[:, width] = 10
+                    f.write(body.tobytes())
+                if full < asc.size:
+                    f.write(asc[full:].tobytes() + b"\n")
+
+
+def gen_reads(torch, dev, contigs, n_reads, L, seed, bound=0.6, indels=True):
+    """PAR-CLIP reads with the distribution of para-suite_amd/simulate.py, generated on the device.
+    Returns uint8 codes [n_reads, L] on the host."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    sizes = torch.tensor([c.numel() for _, c in contigs], dtype=torch.float64)
+    flat = torch.cat([c for _, c in contigs])
+    offs = torch.cumsum(torch.tensor([0] + [c.numel() for _, c in contigs[:-1]]), 0).to(dev)
+    span = L + 2
+    out = torch.empty((n_reads, L), dtype=torch.uint8)
+    comp = torch.tensor([3, 2, 1, 0, 4], dtype=torch.uint8, device=dev)
+    cdf = torch.cumsum(torch.tensor(PROFILE, dtype=torch.float32, device=dev), 1)
+    site = torch.tensor(SITE_FREQ, dtype=torch.float32, device=dev)
+    ar = torch.arange(span, device=dev)
+    jj = torch.arange(L, device=dev)[None, :]
+    chunk = 500_000          # larger chunks trip a torch-ROCm indexing limit (rows beyond 655360 came back wrong)
+    for a in range(0, n_reads, chunk):
+        n = min(chunk, n_reads - a)
+        cidx = torch.multinomial((sizes / sizes.sum()).float().to(dev), n, replacement=True, generator=g)
+        csz = torch.tensor([c.numel() for _, c in contigs], device=dev)[cidx]
+        start = (torch.rand(n, generator=g, device=dev, dtype=torch.float64) * (csz - span)).long()
+        win = flat[(offs[cidx] + start)[:, None] + ar[None, :]]
+        for _ in range(8):                                    # re-draw windows that touch an N run
+            bad = (win == 4).any(1)
+            nb = int(bad.sum())
+            if nb == 0:
+                break
+            s2 = (torch.rand(nb, generator=g, device=dev, dtype=torch.float64) * (csz[bad] - span)).long()
+            start[bad] = s2
+            win[bad] = flat[(offs[cidx[bad]] + s2)[:, None] + ar[None, :]]
+        win[win == 4] = 0
+        strand = torch.rand(n, generator=g, device=dev) < 0.5
+        isb = torch.rand(n, generator=g, device=dev) < bound
+        has_ins = torch.zeros(n, dtype=torch.bool, device=dev)
+        has_del = torch.zeros(n, dtype=torch.bool, device=dev)
+        if indels:
+            u = torch.rand(n, generator=g, device=dev)
+            p_ins, p_del = 1 - (1 - INS_RATE) ** L, 1 - (1 - DEL_RATE) ** L
+            has_ins = u < p_ins
+            has_del = (~has_ins) & (u < p_ins + p_del)
+        ipos = (6 + torch.rand(n, generator=g, device=dev) * max(L - 12, 1)).long()
+        ref_len = L + has_del.long() - has_ins.long()
+        src = torch.where(strand[:, None], ref_len[:, None] - 1 - ar[None, :], ar[None, :]).clamp_(0, span - 1)
+        true = torch.gather(win, 1, src)
+        true = torch.where(strand[:, None], comp[true.long()], true)
+        tpos = (jj + (has_del[:, None] & (jj >= ipos[:, None])).long() - (has_ins[:, None] & (jj > ipos[:, None])).long()).clamp_(0, span - 1)
+        read = torch.gather(true, 1, tpos)
+        ins_here = has_ins[:, None] & (jj == ipos[:, None])
+        read = torch.where(ins_here, torch.randint(0, 4, (n, L), generator=g, device=dev, dtype=torch.uint8), read)
+        # T->C conversions on bound reads: up to 4 random T sites, site j converted with SITE_FREQ[j]
+        prio = torch.where(read == 3, torch.rand((n, L), generator=g, device=dev), torch.full((n, L), 2.0, device=dev))
+        val, order = torch.topk(prio, 4, dim=1, largest=False)
+        conv = (val < 1.5) & (torch.rand((n, 4), generator=g, device=dev) < site[None, :]) & isb[:, None]
+        read.scatter_(1, order, torch.where(conv, torch.ones_like(order, dtype=torch.uint8), torch.gather(read, 1, order)))
+        # sequencing errors by the profile row of the (converted) base
+        u = torch.rand((n, L), generator=g, device=dev)
+        row = cdf[read.long()]
+        read = ((u > row[..., 0]).to(torch.uint8) + (u > row[..., 1]).to(torch.uint8) + (u > row[..., 2]).to(torch.uint8))
+        out[a:a + n] = read.cpu()
+    return out.numpy()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU")
+    ap.add_argument("--read-len", type=int, default=50)
+    ap.add_argument("--genome-mbp", type=int, default=1000)
+    ap.add_argument("--contigs", type=int, default=8)
+    ap.add_argument("--workload", choices=["full", "exact"], default="full")
+    ap.add_argument("--cpu-sample", type=int, default=40000, help="reads of the same workload timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--keep", default="")
+    args = ap.parse_args()
+
+    import torch
+    import capi
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    threads = args.threads or min(16, max(1, (os.cpu_count() or 8) // max(1, world)))
+    log = (lambda *a: print("[bench r%d]" % rank, *a, file=sys.stderr, flush=True))
+
+    # ---------------- data: genome on every rank (same seed), index built on rank 0 ----------------
+    t0 = time.time()
+    contigs = gen_genome(torch, dev, args.genome_mbp * 1_000_000, args.contigs, 0x5EED0002)
+    tmpdir = args.keep or tempfile.mkdtemp(prefix="psbench_")
+    os.makedirs(tmpdir, exist_ok=True)
+    fa = os.path.join(tmpdir, "genome.fa")
+    ctx = None
+    if rank == 0:
+        write_fasta(fa, contigs)
+        log("genome %.1f Mbp written in %.1fs" % (args.genome_mbp, time.time() - t0))
+        t1 = time.time()
+        ctx = capi.Ctx.build(fa, device=local)
+        info = ctx.info()
+        log("index built in %.1fs (library %.0f ms, %d doubling rounds, %.2f GB in HBM)" %
+            (time.time() - t1, info.build_ms, info.sa_rounds, info.device_bytes / 1e9))
+    if world > 1:
+        # one-off broadcast of the index blobs over xGMI (RCCL); rank 0 copies device-to-device into the send buffers
+        t1 = time.time()
+        obj = [None]
+        if rank == 0:
+            obj = [(ctx.meta(), [ctx.blob(i)[1] for i in range(3)])]
+        dist.broadcast_object_list(obj, src=0)
+        meta, sizes = obj[0]
+        blobs = [torch.empty(s, dtype=torch.uint8, device=dev) for s in sizes]
+        if rank == 0:
+            for i in range(3):
+                ctx.export_blob(i, blobs[i].data_ptr(), sizes[i])
+        torch.cuda.synchronize()
+        for b in blobs:
+            dist.broadcast(b, src=0)
+        torch.cuda.synchronize()
+        if rank != 0:
+            ctx = capi.Ctx.from_blobs(meta, local, [b.data_ptr() for b in blobs], keep=blobs)
+        log("index broadcast %.2f GB in %.2fs" % (sum(sizes) / 1e9, time.time() - t1))
+    if args.workload == "exact":
+        ctx.set_stock("0")
+    else:
+        P = np.array(PROFILE)
+        P[3, 1], P[3, 3] = 0.12, 0.87       # the T->C rate a first mapping pass of PAR-CLIP data yields
+        ctx.set_profile(P, INS_RATE, DEL_RATE, -1)
+
+    t1 = time.time()
+    codes = gen_reads(torch, dev, contigs, args.reads, args.read_len, 0x5EED0003 + rank, indels=(args.workload == "full"))
+    del contigs
+    torch.cuda.empty_cache()
+    batch = ctx.batch_from_codes(codes)
+    log("%d reads generated, packed and uploaded in %.1fs" % (args.reads, time.time() - t1))
+
+    chain = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def step():
+        batch.search()
+        before = 0
+        if world > 1 and rank > 0:                      # tie-break stream position handed down the ranks
+            dist.recv(chain, src=rank - 1)
+            before = int(chain.item())
+        after = batch.select_hard(before)
+        if world > 1 and rank < world - 1:
+            chain.fill_(after)
+            dist.send(chain, dst=rank + 1)
+        batch.select_easy(threads)
+        batch.locate()
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    acc = {}
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        tm = batch.timing()
+        for k, v in tm.items():
+            acc[k] = acc.get(k, 0) + v
+    sync()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        K = max(1, args.steps)
+        ks_bt, ks_w, ks_sa = batch.kstats(1), batch.kstats(0), batch.kstats(2)
+        n_bt = max(1, acc["n_backtrack_launches"])
+        ms_bt = acc["ms_backtrack"] / n_bt
+        # algorithmic bytes of one launch: 64 B x distinct Occ blocks touched by its search steps
+        alg_bt = 64.0 * (2 * ks_bt["occ_pairs"] - ks_bt["occ_same_blk"])
+        alg_w = 64.0 * (2 * ks_w["occ_pairs"] - ks_w["occ_same_blk"])
+        ms_w = acc["ms_width"] / max(1, acc["n_width_launches"])
+        dominant_bt = acc["ms_backtrack"] >= acc["ms_width"]
+        ach = (alg_bt / (ms_bt * 1e-3) if dominant_bt else alg_w / (ms_w * 1e-3)) / 1e9
+        hits = batch.hits()
+        res = {
+            "metric": "aligned reads/sec (10Mx50bp PAR-CLIP vs hg19-scale genome) on MI355X; SAM bit-exact vs CPU oracle",
+            "value": world * args.reads * args.steps / elapsed,
+            "unit": "reads/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / K,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "configs[2]: %dx%dbp simulated PAR-CLIP reads per GPU, %s, vs %d Mbp synthetic genome "
+                                   "(hg19 scale model; 32-bit index)" % (args.reads, args.read_len,
+                                   "error-profile seed + banded extension" if args.workload == "full" else "exact-match seed only",
+                                   args.genome_mbp),
+                       "reads_per_gpu": args.reads, "read_len": args.read_len, "genome_mbp": args.genome_mbp,
+                       "mode": args.workload, "parallelism": "reads sharded x%d, index replicated" % world},
+            "roofline": {"bound": "hbm", "kernel": "k_backtrack" if dominant_bt else "k_width",
+                         "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bt if dominant_bt else alg_w,
+                         "avg_launch_ms": ms_bt if dominant_bt else ms_w},
+            "kernels_ms_per_step": {k: acc[k] / K for k in ("ms_width", "ms_backtrack", "ms_compact", "ms_select", "ms_sa2pos",
+                                                            "ms_refine", "ms_host_post")},
+            "kstats": {"backtrack": ks_bt, "width": ks_w, "sa2pos": ks_sa},
+            "mapped_frac": float((hits["type"] != 0).mean()),
+            "overflow_reads": [int(acc["n_overflow_tier1"] / K), int(acc["n_overflow_tier2"] / K)],
+        }
+        # ---------------- CPU baseline: the oracle (a port, not the PARA-suite_aligner binary) ----------------
+        if world == 1 and args.cpu_sample > 0:
+            try:
+                import orc
+                import simulate as S
+                t2 = time.time()
+                ns = min(args.cpu_sample, args.reads)
+                sim = dict(codes=codes[:ns], lens=np.full(ns, args.read_len, dtype=np.int32),
+                           quals=np.full((ns, args.read_len), 73, dtype=np.uint8))
+                fq = os.path.join(tmpdir, "sample.fq")
+                S.write_fastq(fq, sim, names=["r%d" % i for i in range(ns)])
+                info = ctx.info()
+                oix = orc.Index.from_parts(fa, ctx.bwt_syms_chunked(), info.primary, ctx.fetch(1).view("<u4").astype(np.uint64))
+                if args.workload == "exact":
+                    oopt = orc.stock_opt("0")
+                else:
+                    oopt = orc.profile_opt(P, INS_RATE, DEL_RATE, -1)
+                cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+                cores = min(cores, int(os.environ.get("PS_CPU_THREADS", "16")))   # the GPU box grants 16 host cores per GPU
+                log("oracle index adopted in %.1fs; timing %d reads on %d threads" % (time.time() - t2, ns, cores))
+                osam = os.path.join(tmpdir, "sample.orc.sam")
+                r = oix.map_fastq(oopt, fq, osam, n_threads=cores)
+                cpu_rate = ns / (r["t_aln"] + r["t_samse"])
+                res["cpu_baseline"] = {"value": cpu_rate, "unit": "reads/s", "cores": cores, "kind": "port",
+                                       "sample": "first %d reads of the same batch; oracle aln+samse stages incl. SAM formatting; "
+                                                 "CPU restatement, not the PARA-suite_aligner binary" % ns}
+                # parity of the same sample through the product
+                sb = ctx.batch_from_codes(codes[:ns])
+                sb.run(threads)
+                gsam = os.path.join(tmpdir, "sample.gpu.sam")
+                sb.write_sam(gsam, header=False, threads=threads)
+                def strip(path):          # drop QNAME and QUAL (the device batch was built from codes, without qualities)
+                    out = []
+                    for l in open(path):
+                        if not l.startswith("@"):
+                            f = l.rstrip("\n").split("\t")
+                            out.append("\t".join(f[1:10] + f[11:]))
+                    return out
+                g_l, o_l = strip(gsam), strip(osam)
+                # the RNG stream position differs between "first ns reads alone" and the oracle's identical run: both start at 0
+                res["parity_sample"] = {"reads": ns, "identical_sam_lines": int(sum(a == b for a, b in zip(g_l, o_l))),
+                                        "all_identical": g_l == o_l}
+                sb.free()
+            except Exception as e:  # the baseline is a reported extra; never hide the GPU result
+                res["cpu_baseline"] = {"value": None, "unit": "reads/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

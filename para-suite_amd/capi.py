@@ -39,7 +39,7 @@ HIT_DTYPE = np.dtype([("pos", "<i8"), ("sa", "<u4"), ("type", "<i4"), ("strand",
 
 EXPORTS = ["ps_version", "ps_last_error", "ps_index", "ps_map", "ps_ctx_open", "ps_ctx_build", "ps_ctx_close",
            "ps_ctx_set_stock", "ps_ctx_set_profile", "ps_ctx_set_profile_matrix", "ps_ctx_set_tiers", "ps_ctx_info",
-           "ps_ctx_blob", "ps_ctx_meta", "ps_ctx_from_blobs", "ps_ctx_fetch", "ps_batch_from_fastq",
+           "ps_ctx_blob", "ps_ctx_meta", "ps_ctx_from_blobs", "ps_ctx_fetch", "ps_ctx_export_blob", "ps_batch_from_fastq",
            "ps_batch_from_codes", "ps_batch_free", "ps_batch_n", "ps_batch_search", "ps_batch_select_hard",
            "ps_batch_select_easy", "ps_batch_locate", "ps_batch_run", "ps_batch_write_sam", "ps_batch_n_aln",
            "ps_batch_alns", "ps_batch_hits", "ps_batch_timing", "ps_batch_kstats"]
@@ -75,6 +75,7 @@ def lib():
     L.ps_ctx_from_blobs.argtypes = [C.c_char_p, C.c_int64, C.c_int, P(C.c_void_p)]
     L.ps_ctx_from_blobs.restype = C.c_void_p
     L.ps_ctx_fetch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]
+    L.ps_ctx_export_blob.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]
     L.ps_batch_from_fastq.argtypes = [C.c_void_p, C.c_char_p]
     L.ps_batch_from_fastq.restype = C.c_void_p
     L.ps_batch_from_codes.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
@@ -178,6 +179,20 @@ class Ctx:
         out = np.empty(n, dtype=np.uint8)
         _chk(lib().ps_ctx_fetch(self.h, which, out.ctypes.data, n))
         return out
+
+    def export_blob(self, which, dev_ptr, nbytes):
+        _chk(lib().ps_ctx_export_blob(self.h, which, dev_ptr, nbytes))
+
+    def bwt_syms_chunked(self, chunk_blocks=1 << 20):
+        """BWT symbol string (1 byte/symbol) decoded block-wise; for genomes too big for bwt_syms()."""
+        info = self.info()
+        blk = self.fetch(0).view("<u4").reshape(-1, 16)
+        out = np.empty(blk.shape[0] * 192, dtype=np.uint8)
+        sh = (np.arange(16, dtype=np.uint32) * 2)[None, None, :]
+        for a in range(0, blk.shape[0], chunk_blocks):
+            w = blk[a:a + chunk_blocks, 4:]
+            out[a * 192:(a + w.shape[0]) * 192] = ((w[:, :, None] >> sh) & 3).astype(np.uint8).reshape(-1)
+        return out[:info.seq_len]
 
     def bwt_syms(self):
         """Decode the Occ blocks back into the BWT symbol string (tests: compare with the oracle's BWT)."""

@@ -151,6 +151,17 @@ int ps_ctx_fetch(ps_ctx *x, int which, void *dst, uint64_t bytes)
     PS_CATCH_INT
 }
 
+int ps_ctx_export_blob(ps_ctx *x, int which, void *dst, uint64_t bytes)
+{
+    PS_TRY
+        void *p; uint64_t n;
+        if (ps_ctx_blob(x, which, &p, &n)) return 1;
+        if (bytes != n) throw Error("export size differs from blob size");
+        PS_HIP(hipMemcpy(dst, p, bytes, hipMemcpyDeviceToDevice));
+        return 0;
+    PS_CATCH_INT
+}
+
 ps_batch *ps_batch_from_fastq(ps_ctx *x, const char *fastq)
 {
     PS_TRY

@@ -1,0 +1,98 @@
+"""Host-side mirror of the reference's mapping classes for the hot path.
+
+Same names, argument meaning and error behaviour as
+  Mapping.executeMapping(int threads, String reference, String input, String outputPrefix,
+                         int mappingQualityFilter, String additionalOptions)   (Mapping.java:40-42)
+  PARAsuiteMapping (+ setErrorProfileFilename / setIndelProfileFilename)      (PARAsuiteMapping.java:22-154)
+  BWAMapping                                                                    (BWAMapping.java:20-128)
+with the three `bwa` child processes replaced by calls into libparasuite_hip.so.  What the Java does
+after `bwa samse` -- samtools view -bS / view -q, rm, mv (PARAsuiteMapping.java:102-152) -- is BAM
+plumbing outside the hot path; here `<prefix>.sam` is left for it, and the MAPQ
+filter is offered on the SAM text so the output contract can be tested without samtools.
+"""
+import os
+import time
+
+from . import capi
+
+
+class ExternalCallErrorException(Exception):
+    """mirror of mapping.ExternalCallErrorException: the failing 'command' is carried along"""
+
+    def __init__(self, command):
+        super().__init__(command)
+        self.command = command
+
+    def getMappingCommand(self):
+        return self.command
+
+
+class Mapping:
+    """abstract mirror of mapping.Mapping (Mapping.java:26-206)"""
+
+    def __init__(self):
+        self._t0 = None
+
+    def executeMapping(self, threads, reference, input, outputPrefix, mappingQualityFilter, additionalOptions):
+        raise NotImplementedError
+
+    def setTimeStart(self):
+        self._t0 = time.time()
+
+    def calculatePassedTime(self):
+        return int(time.time() - self._t0)          # whole seconds, as Mapping.java:203-206
+
+    def _call(self, what, fn, *args):
+        """Mapping.executeCommand's contract (Mapping.java:151-198): non-zero status => abort with the command"""
+        try:
+            fn(*args)
+        except capi.PsError as e:
+            raise ExternalCallErrorException("%s: %s" % (what, e))
+
+    @staticmethod
+    def filter_sam_mapq(sam_in, sam_out, min_mapq):
+        """what `samtools view -q Q` keeps (PARAsuiteMapping.java:121-133), on SAM text"""
+        with open(sam_in) as fi, open(sam_out, "w") as fo:
+            for line in fi:
+                if line.startswith("@") or int(line.split("\t", 5)[4]) >= min_mapq:
+                    fo.write(line)
+
+
+class BWAMapping(Mapping):
+    """first pass with stock penalties: `bwa aln -t T -n <mm>` + `bwa samse` (BWAMapping.java:51-75)"""
+
+    def executeMapping(self, threads, reference, input, outputPrefix, mappingQualityFilter, additionalOptions):
+        if not os.path.exists(reference + ".bwt"):                      # BWAMapping.java:35-45
+            self._call("bwa index " + reference, capi.ps_index, reference)
+        self.setTimeStart()
+        self._call("bwa aln -t %d -n %s %s %s | bwa samse" % (threads, additionalOptions, reference, input),
+                   capi.ps_map, threads, additionalOptions, None, None, reference, input, outputPrefix + ".sam")
+        self.seconds = self.calculatePassedTime()
+
+
+class PARAsuiteMapping(Mapping):
+    """refine pass with the error profile: `bwa parasuite -t T -X mm -p EP -g IP` + `bwa samse`
+    (PARAsuiteMapping.java:63-92)"""
+
+    def __init__(self):
+        super().__init__()
+        self.errorProfileFilename = None
+        self.indelProfileFilename = None
+
+    def setErrorProfileFilename(self, errorProfileFilename):
+        self.errorProfileFilename = errorProfileFilename
+
+    def setIndelProfileFilename(self, indelProfileFilename):
+        self.indelProfileFilename = indelProfileFilename
+
+    def executeMapping(self, threads, reference, input, outputPrefix, mappingQualityFilter, additionalOptions):
+        if not os.path.exists(reference + ".bwt"):                      # PARAsuiteMapping.java:45-55
+            self._call("bwa index " + reference, capi.ps_index, reference)
+        self.setTimeStart()
+        if not self.errorProfileFilename:
+            raise ExternalCallErrorException("bwa parasuite: no error profile set (-p)")
+        self._call("bwa parasuite -t %d -X %s -p %s -g %s %s %s | bwa samse" %
+                   (threads, additionalOptions, self.errorProfileFilename, self.indelProfileFilename, reference, input),
+                   capi.ps_map, threads, additionalOptions, self.errorProfileFilename, self.indelProfileFilename,
+                   reference, input, outputPrefix + ".sam")
+        self.seconds = self.calculatePassedTime()

@@ -34,9 +34,12 @@ COMP = np.array([3, 2, 1, 0, 4], dtype=np.uint8)
 
 def make_contig(n_bp, rng, n_runs=(), softmask_frac=0.39, at=0.295):
     """ASCII bases of one contig: i.i.d. with hg19-like composition, N runs, soft-masked blocks."""
-    p = np.array([at, 0.5 - at, 0.5 - at, at])
-    codes = rng.choice(4, size=n_bp, p=p).astype(np.uint8)
-    asc = BASES[codes].copy()
+    cdf = np.cumsum([at, 0.5 - at, 0.5 - at]).astype(np.float32)
+    asc = np.empty(n_bp, dtype=np.uint8)
+    for a in range(0, n_bp, 1 << 26):                     # chunked: 1 Gbp must not allocate 8-byte temporaries
+        b = min(n_bp, a + (1 << 26))
+        u = rng.random(b - a, dtype=np.float32)
+        asc[a:b] = BASES[(u >= cdf[0]).astype(np.uint8) + (u >= cdf[1]) + (u >= cdf[2])]
     if softmask_frac > 0:
         # alternate upper/lower blocks with geometric lengths so that ~softmask_frac is lower case
         mean_blk = 300.0
