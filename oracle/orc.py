@@ -104,6 +104,8 @@ def lib():
                                 C.c_int, P(C.c_double), P(C.c_double)]
     L.orc_map_fastq.restype = C.c_int64
     L.orc_last_error.restype = C.c_char_p
+    L.orc_set_rng_offset.argtypes = [C.c_uint64]
+    L.orc_get_rng_draws.restype = C.c_uint64
     _LIB = L
     return L
 
@@ -217,15 +219,17 @@ class Index:
             return n, alns, [(x.w, x.bid) for x in w], [(x.w, x.bid) for x in sw]
         return n, alns
 
-    def map_fastq(self, opt, fastq, sam_out, sai_out=None, n_threads=1, want_hits=0):
+    def map_fastq(self, opt, fastq, sam_out, sai_out=None, n_threads=1, want_hits=0, draws_before=0):
         hits = (Hit * want_hits)() if want_hits else None
+        lib().orc_set_rng_offset(int(draws_before))
         ta, ts = C.c_double(), C.c_double()
         n = lib().orc_map_fastq(self.h, C.byref(opt), fastq.encode(), sam_out.encode(),
                                 sai_out.encode() if sai_out else None, hits, want_hits, n_threads,
                                 C.byref(ta), C.byref(ts))
         if n < 0:
             raise RuntimeError("oracle map: " + lib().orc_last_error().decode())
-        return dict(n=n, t_aln=ta.value, t_samse=ts.value, hits=hits)
+        lib().orc_set_rng_offset(0)
+        return dict(n=n, t_aln=ta.value, t_samse=ts.value, hits=hits, draws_after=lib().orc_get_rng_draws())
 
 
 def ksw_global(query, target, w):

@@ -1091,6 +1091,12 @@ static read_t *load_reads(const char *path, int64_t *n_out)
     return R;
 }
 
+/* multi-process runs shard the reads but must keep ONE tie-break stream in input order: a shard
+ * starts the stream after the draws its predecessors consumed and reports where it stopped. */
+static uint64_t g_draws_before = 0, g_draws_after = 0;
+void orc_set_rng_offset(uint64_t draws_before) { g_draws_before = draws_before; }
+uint64_t orc_get_rng_draws(void) { return g_draws_after; }
+
 static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 
 int64_t orc_map_fastq(const orc_index_t *ix, const orc_opt_t *o, const char *fastq, const char *sam_out,
@@ -1134,7 +1140,15 @@ int64_t orc_map_fastq(const orc_index_t *ix, const orc_opt_t *o, const char *fas
     }
     /* ---- samse stage (upstream bwa_sai2sam_se_core) ---- */
     orc_srand48(&rng, 11);
-    for (i = 0; i < n; ++i) aln2seq(&R[i], o->n_occ, &rng); /* one sequential RNG stream over reads */
+    { uint64_t d, x0; for (d = 0; d < g_draws_before; ++d) rng_step(&rng);
+      g_draws_after = g_draws_before; x0 = rng.x;
+      for (i = 0; i < n; ++i) { /* one sequential RNG stream over reads */
+          orc_rng_t before = rng; uint64_t used = 0;
+          aln2seq(&R[i], o->n_occ, &rng);
+          while (before.x != rng.x) { rng_step(&before); ++used; }
+          g_draws_after += used;
+      }
+      (void)x0; }
     lines = (str_t *)calloc((size_t)n + 1, sizeof(str_t));
 #ifdef _OPENMP
 #pragma omp parallel for schedule(dynamic, 256) num_threads(n_threads)

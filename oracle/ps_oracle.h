@@ -132,6 +132,8 @@ int      orc_ksw_global(int qlen, const uint8_t *q, int tlen, const uint8_t *t, 
 int64_t  orc_map_fastq(const orc_index_t *, const orc_opt_t *, const char *fastq, const char *sam_out,
                        const char *sai_out, orc_hit_t *hits, int64_t hits_cap, int n_threads,
                        double *t_aln_s, double *t_samse_s);
+void     orc_set_rng_offset(uint64_t draws_before);   /* shard of a larger input: draws consumed before it */
+uint64_t orc_get_rng_draws(void);                     /* stream position after the last orc_map_fastq */
 const char *orc_last_error(void);
 
 #ifdef __cplusplus
