@@ -151,10 +151,12 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=40000, help="reads of the same workload timed on the CPU oracle (0 = skip)")
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--keep", default="")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal of the N>1 path (index staged through the host)")
     args = ap.parse_args()
 
     import torch
     import capi
+    import sharding
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -168,7 +170,7 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group(args.backend, **({"device_id": dev} if args.backend == "nccl" else {}))
     threads = args.threads or min(16, max(1, (os.cpu_count() or 8) // max(1, world)))
     log = (lambda *a: print("[bench r%d]" % rank, *a, file=sys.stderr, flush=True))
 
@@ -200,8 +202,13 @@ def main():
             for i in range(3):
                 ctx.export_blob(i, blobs[i].data_ptr(), sizes[i])
         torch.cuda.synchronize()
-        for b in blobs:
-            dist.broadcast(b, src=0)
+        for i, b in enumerate(blobs):
+            if args.backend == "nccl":
+                dist.broadcast(b, src=0)
+            else:                                   # gloo rehearsal: stage through host memory
+                hb = b.cpu()
+                dist.broadcast(hb, src=0)
+                blobs[i].copy_(hb)
         torch.cuda.synchronize()
         if rank != 0:
             ctx = capi.Ctx.from_blobs(meta, local, [b.data_ptr() for b in blobs], keep=blobs)
@@ -220,18 +227,11 @@ def main():
     batch = ctx.batch_from_codes(codes)
     log("%d reads generated, packed and uploaded in %.1fs" % (args.reads, time.time() - t1))
 
-    chain = torch.zeros(1, dtype=torch.int64, device=dev)
+    chain = torch.zeros(1, dtype=torch.int64, device=dev if args.backend == "nccl" else "cpu")
 
     def step():
         batch.search()
-        before = 0
-        if world > 1 and rank > 0:                      # tie-break stream position handed down the ranks
-            dist.recv(chain, src=rank - 1)
-            before = int(chain.item())
-        after = batch.select_hard(before)
-        if world > 1 and rank < world - 1:
-            chain.fill_(after)
-            dist.send(chain, dst=rank + 1)
+        sharding.chain_stream_position(dist, rank, world, chain, batch.select_hard)   # tie-break stream handed down the ranks
         batch.select_easy(threads)
         batch.locate()
 
@@ -254,7 +254,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t_start
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -610,7 +610,7 @@ static int match_gap(const orc_index_t *ix, int len, const uint8_t *seq, orc_wid
     h.b = (bucket_t *)calloc((size_t)h.n_buckets, sizeof(bucket_t));
     { entry_t r; memset(&r, 0, sizeof r); r.i = len; r.k = 0; r.l = ix->seq_len; heap_push(&h, &r); }
     while (h.n_entries) {
-        entry_t e; int i, m, m_seed = 0, hit, allow_diff, allow_M, tmp, rem, ndiff;
+        entry_t e; int i, m, m_seed = 0, hit, allow_diff, allow_M, tmp, rem;
         uint64_t k, l, ck[4], cl[4], occ;
         if (h.n_entries > o->max_entries) break;
         heap_pop(&h, &e);
@@ -619,8 +619,8 @@ static int match_gap(const orc_index_t *ix, int len, const uint8_t *seq, orc_wid
         rem = max_units - e.units;
         if (rem < 0) continue;
         m = rem / md->c_min;
-        ndiff = e.n_mm + e.n_gapo + (o->mode_gape ? e.n_gape : 0);
-        if (seed_width) m_seed = o->max_seed_diff - ndiff;
+        /* seed budget in units as well (stock: max_seed_diff - ndiff) */
+        if (seed_width) m_seed = (o->max_seed_diff * md->u_tight - e.units) / md->c_min;
         if (i > 0 && m < width[i - 1].bid) continue;
         hit = 0;
         if (i == 0) hit = 1;

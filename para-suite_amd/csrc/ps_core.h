@@ -368,8 +368,7 @@ PS_HD void bt_iter(const BtArgs &a, BtLane &L, BtMem &m, int &next_r, int r_stri
         bwtint occ = L.l - L.k + 1;
         int rem = L.max_units - L.units;
         int mleft = md.c_min == 1 ? rem : rem / md.c_min;
-        int ndiff = L.n_mm + L.n_gapo + (md.mode_gape ? L.n_gape : 0);
-        int m_seed = md.max_seed_diff - ndiff;
+        int m_seed = (md.max_seed_diff * md.u_tight - L.units) / md.c_min;   // seed budget, in units like the read budget
         bool allow_diff = true, allow_M = true;
         if (i > 0) {
             int b1 = m.cw[i - 1] & 0x7f, b0 = m.cw[i] & 0x7f;

@@ -1,0 +1,147 @@
+"""CPU tier: the device core (para-suite_amd/csrc/ps_core.h) executed lane by lane on the host
+(tests/hostsim) against the oracle.  This exercises the exact kernel state machine -- Occ blocks,
+width chains, per-lane stack with score buckets, SA walk, banded DP -- without a GPU.  It is a test
+harness, not a product path: libparasuite_hip.so has no CPU implementation."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import orc
+import simulate as S
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ALNREC = np.dtype([("k", "<u4"), ("l", "<u4"), ("score", "<u2"), ("units", "<u2"), ("n_mm", "u1"), ("n_gapo", "u1"),
+                   ("n_gape", "u1"), ("n_ins", "u1"), ("n_del", "u1"), ("pad", "u1", 3)])
+
+
+@pytest.fixture(scope="module")
+def hs():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "hostsim")])
+    H = C.CDLL(os.path.join(HERE, "hostsim", "libhostsim.so"))
+    H.hs_index_new.restype = C.c_void_p
+    H.hs_index_new.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64]
+    H.hs_index_free.argtypes = [C.c_void_p]
+    H.hs_occ.argtypes = [C.c_void_p, C.c_int64, C.c_int]
+    H.hs_occ.restype = C.c_uint32
+    H.hs_sa.argtypes = [C.c_void_p, C.c_uint64]
+    H.hs_sa.restype = C.c_uint32
+    H.hs_sizeof_model.restype = C.c_size_t
+    H.hs_sizeof_alnrec.restype = C.c_size_t
+    H.hs_model_stock.argtypes = [C.c_char_p, C.c_int, C.c_void_p]
+    H.hs_model_profile.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int, C.c_void_p]
+    H.hs_aln.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 7
+    H.hs_banded.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    assert H.hs_sizeof_alnrec() == ALNREC.itemsize
+    return H
+
+
+@pytest.fixture(scope="module")
+def sim_index(hs, example):
+    ix = example["orc_index"]
+    bw, sa, pac = ix.bwt_syms(), ix.sa_samples(), ix.pac()
+    h = hs.hs_index_new(bw.ctypes.data, ix.seq_len, ix.primary, sa.ctypes.data, sa.size, 32, pac.ctypes.data, ix.l_pac)
+    yield h
+    hs.hs_index_free(h)
+
+
+def test_occ_blocks_and_sa_walk(hs, sim_index, example):
+    ix = example["orc_index"]
+    rng = np.random.default_rng(0)
+    rows = list(rng.integers(-1, ix.seq_len + 1, 1500)) + [-1, 0, ix.primary - 1, ix.primary, ix.primary + 1, ix.seq_len - 1, ix.seq_len]
+    rows += [191, 192, 193, 383, 384]                      # block edges
+    for k in rows:
+        for c in range(4):
+            assert hs.hs_occ(sim_index, int(k), c) == ix.occ(int(k), c), (k, c)
+    for k in list(rng.integers(0, ix.seq_len + 1, 1500)) + [0, ix.primary, ix.seq_len]:
+        assert hs.hs_sa(sim_index, int(k)) == ix.sa(int(k)) & 0xFFFFFFFF
+
+
+def _run(hs, h, model, codes, n_lanes=64, pool_cap=4096, aln_cap=64):
+    n, L = codes.shape
+    alns = np.zeros((n, aln_cap), dtype=ALNREC)
+    n_aln = np.zeros(n, dtype=np.int32)
+    status = np.zeros(n, dtype=np.uint8)
+    ks = np.zeros(8, dtype=np.uint64)
+    cc = np.ascontiguousarray(codes)
+    hs.hs_aln(h, model, n, L, cc.ctypes.data, n_lanes, pool_cap, aln_cap, None, None, None, alns.ctypes.data,
+              n_aln.ctypes.data, status.ctypes.data, ks.ctypes.data)
+    return alns, n_aln, status, ks
+
+
+def _compare(hs, h, ix, opt, model, codes, **kw):
+    alns, n_aln, status, ks = _run(hs, h, model, codes, **kw)
+    for r in range(codes.shape[0]):
+        n, ref = ix.aln_one(opt, codes[r], cap=64)
+        assert status[r] == 0
+        got = [tuple(int(a[f]) for f in ("k", "l", "n_mm", "n_gapo", "n_gape", "n_ins", "n_del", "score", "units")) for a in alns[r, :n_aln[r]]]
+        exp = [tuple(a[f] for f in ("k", "l", "n_mm", "n_gapo", "n_gape", "n_ins", "n_del", "score", "units")) for a in ref]
+        assert n == n_aln[r] and got == exp, r
+    return ks
+
+
+@pytest.mark.parametrize("n_arg", ["0.04", "2", "0", "4"])
+def test_lane_machine_stock(hs, sim_index, example, n_arg):
+    sim = S.simulate_reads(example["genome"], 500, 50, seed=3, indel_scale=40, n_frac=0.002)
+    model = (C.c_uint8 * hs.hs_sizeof_model())()
+    assert hs.hs_model_stock(n_arg.encode(), 50, model) == 0
+    ks = _compare(hs, sim_index, example["orc_index"], orc.stock_opt(n_arg), model, sim["codes"])
+    assert ks[0] > 0
+
+
+@pytest.mark.parametrize("x", [-1, 2, 1])
+def test_lane_machine_profile(hs, sim_index, example, x):
+    P = S.EXAMPLE_PROFILE.copy()
+    P[3, 1], P[3, 3] = 0.12, 0.87
+    Pc = np.ascontiguousarray(P.reshape(16))
+    sim = S.simulate_reads(example["genome"], 400, 50, seed=4, indel_scale=40)
+    model = (C.c_uint8 * hs.hs_sizeof_model())()
+    assert hs.hs_model_profile(Pc.ctypes.data, 2.1e-5, 5.9e-4, x, 50, model) == 0
+    _compare(hs, sim_index, example["orc_index"], orc.profile_opt(P, 2.1e-5, 5.9e-4, x), model, sim["codes"])
+
+
+@pytest.mark.parametrize("L", [14, 20, 32, 33, 36, 75, 101])
+def test_lane_machine_lengths(hs, sim_index, example, L):
+    sim = S.simulate_reads(example["genome"], 150, L, seed=5 + L, indel_scale=40)
+    model = (C.c_uint8 * hs.hs_sizeof_model())()
+    assert hs.hs_model_stock(b"0.04", L, model) == 0
+    _compare(hs, sim_index, example["orc_index"], orc.stock_opt("0.04"), model, sim["codes"])
+
+
+def test_lane_reuse_and_few_lanes(hs, sim_index, example):
+    """a lane maps many reads in turn (static read assignment r = lane + j*n_lanes)"""
+    sim = S.simulate_reads(example["genome"], 300, 50, seed=17, indel_scale=40)
+    model = (C.c_uint8 * hs.hs_sizeof_model())()
+    assert hs.hs_model_stock(b"0.04", 50, model) == 0
+    _compare(hs, sim_index, example["orc_index"], orc.stock_opt("0.04"), model, sim["codes"], n_lanes=3)
+
+
+def test_pool_overflow_is_reported(hs, sim_index, example):
+    sim = S.simulate_reads(example["genome"], 100, 50, seed=18)
+    model = (C.c_uint8 * hs.hs_sizeof_model())()
+    assert hs.hs_model_stock(b"0.04", 50, model) == 0
+    _, _, status, _ = _run(hs, sim_index, model, sim["codes"], pool_cap=8)
+    assert (status == 1).any()                               # RS_OVERFLOW_POOL -> the host escalates the tier
+
+
+def test_banded_dp_matches_oracle(hs, sim_index, example):
+    fwd = example["orc_index"].forward_codes()
+    rng = np.random.default_rng(6)
+    for trial in range(40):
+        p = int(rng.integers(20000, 200000))
+        tlen = 50 + int(rng.integers(-3, 4))
+        t = fwd[p:p + tlen]
+        q = list(fwd[p:p + 50])
+        if tlen > 50:
+            q = list(fwd[p:p + 20]) + list(fwd[p + 20 + (tlen - 50):p + tlen])
+        elif tlen < 50:
+            ins = rng.integers(0, 4, 50 - tlen).tolist()
+            q = list(fwd[p:p + 20]) + ins + list(fwd[p + 20:p + tlen])
+        q = np.array(q[:50] + [0] * (50 - len(q[:50])), dtype=np.uint8)
+        w = max(50, int(abs(tlen - 50) * 1.5))
+        cig = (C.c_uint32 * 16)()
+        n = hs.hs_banded(sim_index, 50, q.ctypes.data, p, tlen, w, cig, 16)
+        got = [(c >> 4, "MIDS"[c & 0xF]) for c in cig[:n]]
+        assert got == orc.ksw_global(q, t, w), trial
