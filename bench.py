@@ -150,6 +150,7 @@ def main():
     ap.add_argument("--workload", choices=["full", "exact"], default="full")
     ap.add_argument("--cpu-sample", type=int, default=40000, help="reads of the same workload timed on the CPU oracle (0 = skip)")
     ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--penalty", choices=["profile", "stock"], default="profile", help="full workload: PAR-CLIP error-profile costs (bwa parasuite) or stock costs (bwa aln -n 0.04)")
     ap.add_argument("--keep", default="")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal of the N>1 path (index staged through the host)")
     args = ap.parse_args()
@@ -215,6 +216,8 @@ def main():
         log("index broadcast %.2f GB in %.2fs" % (sum(sizes) / 1e9, time.time() - t1))
     if args.workload == "exact":
         ctx.set_stock("0")
+    elif args.penalty == "stock":
+        ctx.set_stock("0.04")
     else:
         P = np.array(PROFILE)
         P[3, 1], P[3, 3] = 0.12, 0.87       # the T->C rate a first mapping pass of PAR-CLIP data yields
@@ -283,7 +286,7 @@ def main():
                                    "error-profile seed + banded extension" if args.workload == "full" else "exact-match seed only",
                                    args.genome_mbp),
                        "reads_per_gpu": args.reads, "read_len": args.read_len, "genome_mbp": args.genome_mbp,
-                       "mode": args.workload, "parallelism": "reads sharded x%d, index replicated" % world},
+                       "mode": args.workload, "penalty": args.penalty, "parallelism": "reads sharded x%d, index replicated" % world},
             "roofline": {"bound": "hbm", "kernel": "k_backtrack" if dominant_bt else "k_width",
                          "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
                          "algorithmic_bytes_per_launch": alg_bt if dominant_bt else alg_w,
@@ -309,6 +312,8 @@ def main():
                 oix = orc.Index.from_parts(fa, ctx.bwt_syms_chunked(), info.primary, ctx.fetch(1).view("<u4").astype(np.uint64))
                 if args.workload == "exact":
                     oopt = orc.stock_opt("0")
+                elif args.penalty == "stock":
+                    oopt = orc.stock_opt("0.04")
                 else:
                     oopt = orc.profile_opt(P, INS_RATE, DEL_RATE, -1)
                 cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)

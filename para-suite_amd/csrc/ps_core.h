@@ -181,14 +181,60 @@ struct BtLane {
     LaneStats st;
 };
 
-// local per-lane memory (LDS in the kernel): cw[len+1], csw[seed_len+1], seq[len]
-PS_HD int lm_bytes(int len, int seed_len) { int n = (len + 1) + (seed_len + 1) + len; n = (n + 3) & ~3; if (((n >> 2) & 1) == 0) n += 4; return n; }
+// local per-lane memory (LDS in the kernel): cw[len+1], csw[seed_len+1], seq[len], then -- narrow stack
+// only -- the heads of the score buckets as uint16 entry indices.  The byte count keeps (stride/4) odd so
+// that lanes reading the same offset hit different LDS banks.
+PS_HD int lm_heads_off(int len, int seed_len) { return ((len + 1) + (seed_len + 1) + len + 1) & ~1; }
+PS_HD int lm_bytes(int len, int seed_len, int n_buckets, bool wide)
+{
+    int n = lm_heads_off(len, seed_len) + (wide ? 0 : 2 * n_buckets);
+    n = (n + 3) & ~3;
+    if (((n >> 2) & 1) == 0) n += 4;
+    return n;
+}
 
 struct BtMem {              // views of one lane's slices
     uint8_t *cw, *csw, *seq;
-    Entry *pool; uint32_t *heads;
+    uint16_t *heads16;      // narrow: in local memory
+    void *pool;             // narrow: Entry16[pool_cap]; wide: Entry[pool_cap]
+    uint32_t *heads;        // wide: global, PS_MAX_BUCKETS per lane
 };
 
+// The stack of one lane.  NARROW (tiers 1-2): 16-byte entries, bump allocation, bucket heads in LDS --
+// one 16-byte global store per push and one 16-byte load per pop.  WIDE (last tier, up to the 2,000,000
+// live entries upstream allows): 32-byte entries with a free list and heads in global memory.
+struct Entry16 { uint32_t k, l, a, b; };
+static const uint32_t PS_NIL16 = 0xFFFFu;
+
+PS_HD bool bm_test(const BtLane &L, int b) { return (L.bm[b >> 6] >> (b & 63)) & 1ull; }
+PS_HD void bm_set(BtLane &L, int b) { L.bm[b >> 6] |= 1ull << (b & 63); }
+PS_HD void bm_clr(BtLane &L, int b) { L.bm[b >> 6] &= ~(1ull << (b & 63)); }
+PS_HD int bm_first(const BtLane &L)
+{
+#ifdef __HIP_DEVICE_COMPILE__
+    return L.bm[0] ? (__ffsll((unsigned long long)L.bm[0]) - 1) : (64 + __ffsll((unsigned long long)L.bm[1]) - 1);
+#else
+    return L.bm[0] ? __builtin_ctzll(L.bm[0]) : 64 + __builtin_ctzll(L.bm[1]);
+#endif
+}
+
+PS_HD void store16(Entry16 *dst, const Entry16 &e)
+{
+#ifdef __HIP_DEVICE_COMPILE__
+    *reinterpret_cast<uint4 *>(dst) = make_uint4(e.k, e.l, e.a, e.b);
+#else
+    *dst = e;
+#endif
+}
+PS_HD void load16(const Entry16 *src, Entry16 &e)
+{
+#ifdef __HIP_DEVICE_COMPILE__
+    uint4 v = *reinterpret_cast<const uint4 *>(src);
+    e.k = v.x; e.l = v.y; e.a = v.z; e.b = v.w;
+#else
+    e = *src;
+#endif
+}
 PS_HD void store_entry(Entry *dst, const Entry &e)
 {
 #ifdef __HIP_DEVICE_COMPILE__
@@ -210,38 +256,73 @@ PS_HD void load_entry(const Entry *src, Entry &e)
 #endif
 }
 
-PS_HD bool bm_test(const BtLane &L, int b) { return (L.bm[b >> 6] >> (b & 63)) & 1ull; }
-PS_HD void bm_set(BtLane &L, int b) { L.bm[b >> 6] |= 1ull << (b & 63); }
-PS_HD void bm_clr(BtLane &L, int b) { L.bm[b >> 6] &= ~(1ull << (b & 63)); }
-PS_HD int bm_first(const BtLane &L)
-{
-#ifdef __HIP_DEVICE_COMPILE__
-    return L.bm[0] ? (__ffsll((unsigned long long)L.bm[0]) - 1) : (64 + __ffsll((unsigned long long)L.bm[1]) - 1);
-#else
-    return L.bm[0] ? __builtin_ctzll(L.bm[0]) : 64 + __builtin_ctzll(L.bm[1]);
-#endif
-}
-
-// push a child entry on its score bucket (LIFO linked list through Entry::next)
+// push a child entry on its score bucket (LIFO linked list through the entries' next field)
+template <bool WIDE>
 PS_HD void bt_push(const BtArgs &a, BtLane &L, BtMem &m, int i, bwtint k, bwtint l, int n_mm, int n_gapo, int n_gape,
                    int n_ins, int n_del, int state, bool is_diff, int score, int units)
 {
     if (units > L.max_units) return;        // cannot be afforded (no-op with stock costs)
-    uint32_t idx;
-    if (L.free_head != PS_NIL) { idx = L.free_head; L.free_head = m.pool[idx].next; }
-    else if (L.bump < a.pool_cap) idx = L.bump++;
-    else { L.status = RS_OVERFLOW_POOL; return; }
-    Entry e;
-    e.k = k; e.l = l; e.score = (uint16_t)score; e.units = (uint16_t)units;
-    e.i = (uint8_t)i; e.last_diff_pos = (uint8_t)(is_diff ? i : 0);
-    e.n_mm = (uint8_t)n_mm; e.n_gapo = (uint8_t)n_gapo; e.n_gape = (uint8_t)n_gape;
-    e.n_ins = (uint8_t)n_ins; e.n_del = (uint8_t)n_del; e.state = (uint8_t)state;
-    e.next = bm_test(L, score) ? m.heads[score] : PS_NIL;
-    e.pad[0] = e.pad[1] = 0;
-    store_entry(&m.pool[idx], e);
-    m.heads[score] = idx;
+    if (WIDE) {
+        Entry *pool = reinterpret_cast<Entry *>(m.pool);
+        uint32_t idx;
+        if (L.free_head != PS_NIL) { idx = L.free_head; L.free_head = pool[idx].next; }
+        else if (L.bump < a.pool_cap) idx = L.bump++;
+        else { L.status = RS_OVERFLOW_POOL; return; }
+        Entry e;
+        e.k = k; e.l = l; e.score = (uint16_t)score; e.units = (uint16_t)units;
+        e.i = (uint8_t)i; e.last_diff_pos = (uint8_t)(is_diff ? i : 0);
+        e.n_mm = (uint8_t)n_mm; e.n_gapo = (uint8_t)n_gapo; e.n_gape = (uint8_t)n_gape;
+        e.n_ins = (uint8_t)n_ins; e.n_del = (uint8_t)n_del; e.state = (uint8_t)state;
+        e.next = bm_test(L, score) ? m.heads[score] : PS_NIL;
+        e.pad[0] = e.pad[1] = 0;
+        store_entry(&pool[idx], e);
+        m.heads[score] = idx;
+    } else {
+        if (L.bump >= a.pool_cap) { L.status = RS_OVERFLOW_POOL; return; }
+        const uint32_t idx = L.bump++;
+        const uint32_t next = bm_test(L, score) ? (uint32_t)m.heads16[score] : PS_NIL16;
+        Entry16 e;
+        e.k = k; e.l = l;
+        e.a = (uint32_t)i | ((uint32_t)(is_diff ? i : 0) << 8) | ((uint32_t)n_mm << 16) |
+              (((uint32_t)state | ((uint32_t)n_gapo << 2) | ((uint32_t)n_gape << 5)) << 24);
+        e.b = (uint32_t)n_ins | ((uint32_t)n_del << 4) | ((uint32_t)score << 8) | (next << 16);
+        store16(reinterpret_cast<Entry16 *>(m.pool) + idx, e);
+        m.heads16[score] = (uint16_t)idx;
+    }
     bm_set(L, score);
     ++L.n_stack; ++L.st.pushes;
+}
+
+// pop the newest entry of the lowest non-empty score bucket into the lane's current-entry registers
+template <bool WIDE>
+PS_HD void bt_pop(const BtArgs &a, BtLane &L, BtMem &m)
+{
+    const int b = bm_first(L);
+    if (WIDE) {
+        Entry *pool = reinterpret_cast<Entry *>(m.pool);
+        uint32_t h = m.heads[b];
+        Entry e;
+        load_entry(&pool[h], e);
+        if (e.next == PS_NIL) bm_clr(L, b); else m.heads[b] = e.next;
+        pool[h].next = L.free_head; L.free_head = h;
+        L.k = e.k; L.l = e.l; L.i = e.i; L.score = e.score; L.units = e.units;
+        L.n_mm = e.n_mm; L.n_gapo = e.n_gapo; L.n_gape = e.n_gape; L.n_ins = e.n_ins; L.n_del = e.n_del;
+        L.state = e.state; L.ldp = e.last_diff_pos;
+    } else {
+        Entry16 e;
+        load16(reinterpret_cast<const Entry16 *>(m.pool) + m.heads16[b], e);
+        const uint32_t next = e.b >> 16;
+        if (next == PS_NIL16) bm_clr(L, b); else m.heads16[b] = (uint16_t)next;
+        L.k = e.k; L.l = e.l;
+        L.i = (int)(e.a & 0xff); L.ldp = (int)((e.a >> 8) & 0xff); L.n_mm = (int)((e.a >> 16) & 0xff);
+        const uint32_t g = e.a >> 24;
+        L.state = (int)(g & 3); L.n_gapo = (int)((g >> 2) & 7); L.n_gape = (int)(g >> 5);
+        L.n_ins = (int)(e.b & 15); L.n_del = (int)((e.b >> 4) & 15);
+        L.score = (int)((e.b >> 8) & 0xff);
+        // units are not stored: profile mode has units == score, stock counts every edit as one unit
+        L.units = a.md.profile ? L.score : L.n_mm + L.n_gapo + (a.md.mode_gape ? L.n_gape : 0);
+    }
+    --L.n_stack; ++L.st.pops;
 }
 
 PS_HD void bt_finish_read(const BtArgs &a, BtLane &L)
@@ -296,6 +377,7 @@ PS_HD void bt_hit(const BtArgs &a, BtLane &L, BtMem &m)
 }
 
 // One iteration of a lane.  next_r: the read this lane takes when it needs one (caller advances it).
+template <bool WIDE>
 PS_HD void bt_iter(const BtArgs &a, BtLane &L, BtMem &m, int &next_r, int r_stride)
 {
     const Model &md = a.md;
@@ -327,18 +409,7 @@ PS_HD void bt_iter(const BtArgs &a, BtLane &L, BtMem &m, int &next_r, int r_stri
         int n_virtual = L.n_stack + (L.have_cur ? 1 : 0);
         if (n_virtual == 0 || n_virtual > md.max_entries || L.status != RS_OK) { bt_finish_read(a, L); return; }
         if (L.have_cur) L.have_cur = false;
-        else {
-            int b = bm_first(L);
-            uint32_t h = m.heads[b];
-            Entry e;
-            load_entry(&m.pool[h], e);
-            if (e.next == PS_NIL) bm_clr(L, b); else m.heads[b] = e.next;
-            m.pool[h].next = L.free_head; L.free_head = h;
-            --L.n_stack; ++L.st.pops;
-            L.k = e.k; L.l = e.l; L.i = e.i; L.score = e.score; L.units = e.units;
-            L.n_mm = e.n_mm; L.n_gapo = e.n_gapo; L.n_gape = e.n_gape; L.n_ins = e.n_ins; L.n_del = e.n_del;
-            L.state = e.state; L.ldp = e.last_diff_pos;
-        }
+        else bt_pop<WIDE>(a, L, m);
         if (L.score > L.best_score + md.s_stop) { bt_finish_read(a, L); return; }
         int rem = L.max_units - L.units;
         if (rem < 0) return;
@@ -392,20 +463,20 @@ PS_HD void bt_iter(const BtArgs &a, BtLane &L, BtMem &m, int &next_r, int r_stri
         if (allow_diff && i >= md.indel_end_skip + tmp && len - i >= md.indel_end_skip + tmp) {
             if (e_st == ST_M) {
                 if (e_go < md.max_gapo) {
-                    bt_push(a, L, m, i, ek, el, e_mm, e_go + 1, e_ge, e_ni + 1, e_nd, ST_I, true, e_sc + md.s_gapo_ins, e_un + md.u_gapo_ins);
+                    bt_push<WIDE>(a, L, m, i, ek, el, e_mm, e_go + 1, e_ge, e_ni + 1, e_nd, ST_I, true, e_sc + md.s_gapo_ins, e_un + md.u_gapo_ins);
                     for (int j = 0; j < 4; ++j) {
                         bwtint nk = a.ix.L2[j] + ck[j] + 1, nl = a.ix.L2[j] + cl[j];
-                        if (nk <= nl) bt_push(a, L, m, i + 1, nk, nl, e_mm, e_go + 1, e_ge, e_ni, e_nd + 1, ST_D, true, e_sc + md.s_gapo_del, e_un + md.u_gapo_del);
+                        if (nk <= nl) bt_push<WIDE>(a, L, m, i + 1, nk, nl, e_mm, e_go + 1, e_ge, e_ni, e_nd + 1, ST_D, true, e_sc + md.s_gapo_del, e_un + md.u_gapo_del);
                     }
                 }
             } else if (e_st == ST_I) {
                 if (e_ge < md.max_gape)
-                    bt_push(a, L, m, i, ek, el, e_mm, e_go, e_ge + 1, e_ni + 1, e_nd, ST_I, true, e_sc + md.s_gape, e_un + md.u_gape);
+                    bt_push<WIDE>(a, L, m, i, ek, el, e_mm, e_go, e_ge + 1, e_ni + 1, e_nd, ST_I, true, e_sc + md.s_gape, e_un + md.u_gape);
             } else {
                 if (e_ge < md.max_gape && ((e_ge + e_go) * md.u_tight < L.max_units || occ < (bwtint)md.max_del_occ)) {
                     for (int j = 0; j < 4; ++j) {
                         bwtint nk = a.ix.L2[j] + ck[j] + 1, nl = a.ix.L2[j] + cl[j];
-                        if (nk <= nl) bt_push(a, L, m, i + 1, nk, nl, e_mm, e_go, e_ge + 1, e_ni, e_nd + 1, ST_D, true, e_sc + md.s_gape, e_un + md.u_gape);
+                        if (nk <= nl) bt_push<WIDE>(a, L, m, i + 1, nk, nl, e_mm, e_go, e_ge + 1, e_ni, e_nd + 1, ST_D, true, e_sc + md.s_gape, e_un + md.u_gape);
                     }
                 }
             }
@@ -418,7 +489,7 @@ PS_HD void bt_iter(const BtArgs &a, BtLane &L, BtMem &m, int &next_r, int r_stri
                 bool is_mm = (j != 4 || s > 3);
                 bwtint nk = a.ix.L2[c] + ck[c] + 1, nl = a.ix.L2[c] + cl[c];
                 if (nk > nl) continue;
-                if (is_mm) bt_push(a, L, m, i, nk, nl, e_mm + 1, e_go, e_ge, e_ni, e_nd, ST_M, true, e_sc + md.s_mm[s][c], e_un + md.u_mm[s][c]);
+                if (is_mm) bt_push<WIDE>(a, L, m, i, nk, nl, e_mm + 1, e_go, e_ge, e_ni, e_nd, ST_M, true, e_sc + md.s_mm[s][c], e_un + md.u_mm[s][c]);
                 else { // the match child has the parent's score and is pushed last: it is the next pop
                     L.k = nk; L.l = nl; L.i = i; L.state = ST_M; L.ldp = 0; L.have_cur = true;
                 }

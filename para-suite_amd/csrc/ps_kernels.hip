@@ -66,6 +66,7 @@ __global__ void __launch_bounds__(256) k_width(WidthArgs a)
 }
 
 // ---- seed / backtracking stage --------------------------------------------
+template <bool WIDE>
 __global__ void __launch_bounds__(256) k_backtrack(BtArgs a, int lm_stride)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -73,13 +74,14 @@ __global__ void __launch_bounds__(256) k_backtrack(BtArgs a, int lm_stride)
     BtMem m;
     uint8_t *mine = smem + (size_t)threadIdx.x * lm_stride;
     m.cw = mine; m.csw = mine + a.len + 1; m.seq = m.csw + a.md.seed_len + 1;
-    m.pool = a.pool + (size_t)lane_g * a.pool_cap;
-    m.heads = a.heads + (size_t)lane_g * PS_MAX_BUCKETS;
+    m.heads16 = reinterpret_cast<uint16_t *>(mine + lm_heads_off(a.len, a.md.seed_len));
+    m.pool = reinterpret_cast<uint8_t *>(a.pool) + (size_t)lane_g * a.pool_cap * (WIDE ? sizeof(Entry) : sizeof(Entry16));
+    m.heads = WIDE ? a.heads + (size_t)lane_g * PS_MAX_BUCKETS : nullptr;
     BtLane L;
     L.mode = M_FETCH; L.r = 0; L.have_cur = false; L.n_stack = 0; L.status = RS_OK; L.n_aln = 0;
     L.st = {0, 0, 0, 0, 0, 0, 0, 0};
     int next_r = lane_g;
-    while (L.mode != M_EXIT) bt_iter(a, L, m, next_r, a.n_lanes);
+    while (L.mode != M_EXIT) bt_iter<WIDE>(a, L, m, next_r, a.n_lanes);
     flush_stats(a.stats, L.st);
 }
 
@@ -139,8 +141,13 @@ void launch_width(const WidthArgs &a, hipStream_t s)
 void launch_backtrack(const BtArgs &a, int n_blocks, int lm_stride, hipStream_t s)
 {
     const size_t lds = (size_t)256 * lm_stride;
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_backtrack), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_backtrack, dim3(n_blocks), dim3(256), lds, s, a, lm_stride);
+    if (a.wide) {
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_backtrack<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_backtrack<true>, dim3(n_blocks), dim3(256), lds, s, a, lm_stride);
+    } else {
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_backtrack<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_backtrack<false>, dim3(n_blocks), dim3(256), lds, s, a, lm_stride);
+    }
 }
 void launch_sa2pos(const IndexView &ix, const bwtint *rows, bwtint *out, int n, KStats *stats, hipStream_t s)
 {

@@ -128,7 +128,7 @@ inline bool read_profile_files(const char *ep, const char *ip, double P[16], dou
 inline bool make_model(const Options &o, int len, Model &m, std::string &err)
 {
     std::memset(&m, 0, sizeof m);
-    m.len = len;
+    m.len = len; m.profile = o.profile ? 1 : 0;
     m.max_gape = o.max_gape; m.mode_gape = o.mode_gape; m.indel_end_skip = o.indel_end_skip;
     m.max_del_occ = o.max_del_occ; m.max_entries = o.max_entries; m.max_seed_diff = o.max_seed_diff; m.max_top2 = o.max_top2;
     m.use_seed = len > o.seed_len; m.seed_len = m.use_seed ? o.seed_len : 0;
@@ -165,6 +165,7 @@ inline bool make_model(const Options &o, int len, Model &m, std::string &err)
     }
     if (m.n_buckets > PS_MAX_BUCKETS) { err = "score range exceeds PS_MAX_BUCKETS; lower -n/-X"; return false; }
     if (len > PS_MAX_LEN) { err = "read longer than PS_MAX_LEN"; return false; }
+    if (m.max_gapo > 7 || m.max_gape > 7) { err = "gap limits above 7 are not supported by the packed stack entry"; return false; }
     if (m.max_units / m.c_min > 126) { err = "difference budget too large"; return false; }
     return true;
 }

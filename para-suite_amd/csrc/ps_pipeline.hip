@@ -181,23 +181,29 @@ static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases
     { EvTimer t(s); launch_width(wa, s); PS_HIP(hipGetLastError()); b.tm.ms_width += t.stop(); ++b.tm.n_width_launches; }
     int dev_cus = 256;
     { hipDeviceProp_t p; if (hipGetDeviceProperties(&p, ctx->device) == hipSuccess && p.multiProcessorCount > 0) dev_cus = p.multiProcessorCount; }
-    int blocks = ctx->bt_blocks > 0 ? ctx->bt_blocks : dev_cus * 4;
+    const bool wide = pool_cap > 65535;                       // narrow entries link with 16-bit indices
+    const int lm = lm_bytes(len, seed_len, md.n_buckets, wide);
+    int per_cu = (int)((size_t)(160 * 1024) / ((size_t)256 * lm));
+    if (per_cu < 1) throw Error("read length / score range too large for the per-lane LDS state");
+    if (per_cu > 4) per_cu = 4;
+    int blocks = ctx->bt_blocks > 0 ? ctx->bt_blocks : dev_cus * per_cu;
     int need = (n + 255) / 256;
     if (blocks > need) blocks = need;
-    // the largest tier keeps 64 MB of stack per lane: bound the lanes by memory
-    size_t per_lane = (size_t)pool_cap * sizeof(Entry) + PS_MAX_BUCKETS * 4;
-    size_t max_lanes = ((size_t)24 << 30) / per_lane;
+    // bound the lanes by stack memory (the widest tier keeps 64 MB per lane)
+    const size_t per_lane = (size_t)pool_cap * (wide ? sizeof(Entry) : 16) + (wide ? PS_MAX_BUCKETS * 4 : 0);
+    const size_t max_lanes = ((size_t)48 << 30) / per_lane;
     if ((size_t)blocks * 256 > max_lanes) blocks = (int)std::max<size_t>(1, max_lanes / 256);
     const int n_lanes = blocks * 256;
-    DevBuf<Entry> pool; DevBuf<uint32_t> heads;
-    pool.alloc((size_t)n_lanes * pool_cap); heads.alloc((size_t)n_lanes * PS_MAX_BUCKETS);
+    DevBuf<uint8_t> pool; DevBuf<uint32_t> heads;
+    pool.alloc((size_t)n_lanes * pool_cap * (wide ? sizeof(Entry) : 16));
+    if (wide) heads.alloc((size_t)n_lanes * PS_MAX_BUCKETS);
     BtArgs a; std::memset(&a, 0, sizeof a);
     a.ix = ctx->ix.view; a.md = md; a.n_reads = n; a.len = len; a.n_lanes = n_lanes;
     a.bases = d_bases; a.nmask = d_nmask; a.n_bw = (len + 15) / 16; a.n_mw = (len + 31) / 32;
     a.w = w.p; a.cwb = cwb.p; a.cswb = cswb.p;
     a.alns = alns.p; a.aln_cap = aln_cap; a.n_aln = n_aln.p; a.status = status.p;
-    a.pool = pool.p; a.pool_cap = pool_cap; a.heads = heads.p; a.stats = b.d_stats.p + 1;
-    { EvTimer t(s); launch_backtrack(a, blocks, lm_bytes(len, seed_len), s); PS_HIP(hipGetLastError()); b.tm.ms_backtrack += t.stop(); ++b.tm.n_backtrack_launches; }
+    a.pool = pool.p; a.pool_cap = pool_cap; a.heads = heads.p; a.wide = wide ? 1 : 0; a.stats = b.d_stats.p + 1;
+    { EvTimer t(s); launch_backtrack(a, blocks, lm, s); PS_HIP(hipGetLastError()); b.tm.ms_backtrack += t.stop(); ++b.tm.n_backtrack_launches; }
     // compact the hit lists on the device, then one download
     EvTimer tc(s);
     DevBuf<uint32_t> cnt, off; cnt.alloc(n); off.alloc(n);

@@ -49,7 +49,7 @@ struct Model {
     int32_t u_gapo_ins, s_gapo_ins, u_gapo_del, s_gapo_del, u_gape, s_gape;
     int32_t s_stop, u_tight, c_min, max_units, n_buckets;
     int32_t max_gapo, max_gape, mode_gape, indel_end_skip, max_del_occ, max_entries;
-    int32_t seed_len, max_seed_diff, max_top2, use_seed, len;
+    int32_t seed_len, max_seed_diff, max_top2, use_seed, len, profile;
 };
 static const int PS_MAX_BUCKETS = 128;
 static const int PS_MAX_LEN = 250;
@@ -91,7 +91,9 @@ struct BtArgs {
     // outputs
     AlnRec *alns; int aln_cap; int32_t *n_aln; uint8_t *status;
     // per-lane scratch
-    Entry *pool; uint32_t pool_cap; uint32_t *heads;   // heads[lane*PS_MAX_BUCKETS + bucket]
+    void *pool; uint32_t pool_cap;                    // per lane: pool_cap entries (16 B narrow / 32 B wide)
+    uint32_t *heads;                                  // wide stack only: heads[lane*PS_MAX_BUCKETS + bucket]
+    int wide;
     KStats *stats;
 };
 

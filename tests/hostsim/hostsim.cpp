@@ -59,7 +59,7 @@ uint32_t hs_sa(void *p, uint64_t row)
 
 // Width stage + backtracking stage for n_reads reads of one length, simulated with n_lanes lanes.
 // codes: [n_reads][len] (0..3, 4 = N).  Outputs: w_out [len+1][n_reads] (pre-shadow), cwb, alns.
-int hs_aln(void *p, const Model *md, int n_reads, int len, const uint8_t *codes, int n_lanes, int pool_cap, int aln_cap,
+int hs_aln(void *p, const Model *md, int n_reads, int len, const uint8_t *codes, int n_lanes, int pool_cap, int aln_cap, int force_wide,
            uint32_t *w_out, uint8_t *cwb_out, uint8_t *cswb_out, AlnRec *alns, int32_t *n_aln, uint8_t *status, KStats *ks)
 {
     SimIndex *s = (SimIndex *)p;
@@ -97,10 +97,11 @@ int hs_aln(void *p, const Model *md, int n_reads, int len, const uint8_t *codes,
     a.bases = bases.data(); a.nmask = nmask.data(); a.n_bw = n_bw; a.n_mw = n_mw;
     a.w = w.data(); a.cwb = cwb.data(); a.cswb = cswb.data();
     a.alns = alns; a.aln_cap = aln_cap; a.n_aln = n_aln; a.status = status;
-    std::vector<Entry> pool((size_t)n_lanes * pool_cap);
+    const bool wide = pool_cap > 65535 || force_wide;
+    std::vector<uint8_t> pool((size_t)n_lanes * pool_cap * (wide ? sizeof(Entry) : sizeof(Entry16)));
     std::vector<uint32_t> heads((size_t)n_lanes * PS_MAX_BUCKETS);
-    a.pool = pool.data(); a.pool_cap = (uint32_t)pool_cap; a.heads = heads.data();
-    int lmb = lm_bytes(len, seed_len);
+    a.pool = pool.data(); a.pool_cap = (uint32_t)pool_cap; a.heads = heads.data(); a.wide = wide;
+    int lmb = lm_bytes(len, seed_len, md->n_buckets, wide);
     std::vector<uint8_t> lm((size_t)n_lanes * lmb);
     std::vector<BtLane> lanes(n_lanes); std::vector<int> next(n_lanes);
     for (int t = 0; t < n_lanes; ++t) { memset(&lanes[t], 0, sizeof(BtLane)); lanes[t].mode = M_FETCH; next[t] = t; }
@@ -112,8 +113,10 @@ int hs_aln(void *p, const Model *md, int n_reads, int len, const uint8_t *codes,
             if (L.mode == M_EXIT) continue;
             BtMem m; uint8_t *mine = lm.data() + (size_t)t * lmb;
             m.cw = mine; m.csw = mine + len + 1; m.seq = m.csw + seed_len + 1;
-            m.pool = a.pool + (size_t)t * pool_cap; m.heads = a.heads + (size_t)t * PS_MAX_BUCKETS;
-            bt_iter(a, L, m, next[t], n_lanes);
+            m.heads16 = reinterpret_cast<uint16_t *>(mine + lm_heads_off(len, seed_len));
+            m.pool = pool.data() + (size_t)t * pool_cap * (wide ? sizeof(Entry) : sizeof(Entry16));
+            m.heads = a.heads + (size_t)t * PS_MAX_BUCKETS;
+            if (wide) bt_iter<true>(a, L, m, next[t], n_lanes); else bt_iter<false>(a, L, m, next[t], n_lanes);
             any = true;
         }
     }
