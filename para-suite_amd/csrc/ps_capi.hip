@@ -1,6 +1,7 @@
 // ps_capi.hip -- extern "C" boundary (include/parasuite_hip.h).  Exceptions stop here.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include "../../include/parasuite_hip.h"
@@ -30,6 +31,9 @@ static ps_ctx *new_ctx(int device)
     ps_ctx *x = new ps_ctx();
     x->c.device = device;
     PS_HIP(hipStreamCreateWithFlags(&x->c.stream, hipStreamNonBlocking));
+    if (const char *e = std::getenv("PS_FETCH_MIN")) x->c.fetch_min = std::atoi(e);       // tuning knobs
+    if (const char *e = std::getenv("PS_BT_BLOCKS")) x->c.bt_blocks = std::atoi(e);
+    if (const char *e = std::getenv("PS_POOL_CAP")) x->c.pool_cap[0] = (uint32_t)std::atoi(e);
     return x;
 }
 

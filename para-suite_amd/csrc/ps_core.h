@@ -181,10 +181,13 @@ struct BtLane {
     LaneStats st;
 };
 
-// local per-lane memory (LDS in the kernel): cw[len+1], csw[seed_len+1], seq[len], then -- narrow stack
-// only -- the heads of the score buckets as uint16 entry indices.  The byte count keeps (stride/4) odd so
-// that lanes reading the same offset hit different LDS banks.
-PS_HD int lm_heads_off(int len, int seed_len) { return ((len + 1) + (seed_len + 1) + len + 1) & ~1; }
+// local per-lane memory (LDS in the kernel), all 4-byte words: compact widths cw (4 positions per word),
+// seed widths csw, the read's 2-bit base words and N-mask words, then -- narrow stack only -- the heads of
+// the score buckets as uint16 entry indices.  The byte count keeps (stride/4) odd so that lanes reading
+// the same offset hit different LDS banks.
+PS_HD int lm_ncw(int len) { return (len + 1 + 3) >> 2; }
+PS_HD int lm_ncsw(int seed_len) { return seed_len > 0 ? (seed_len + 1 + 3) >> 2 : 0; }
+PS_HD int lm_heads_off(int len, int seed_len) { return 4 * (lm_ncw(len) + lm_ncsw(seed_len) + ((len + 15) >> 4) + ((len + 31) >> 5)); }
 PS_HD int lm_bytes(int len, int seed_len, int n_buckets, bool wide)
 {
     int n = lm_heads_off(len, seed_len) + (wide ? 0 : 2 * n_buckets);
@@ -194,11 +197,27 @@ PS_HD int lm_bytes(int len, int seed_len, int n_buckets, bool wide)
 }
 
 struct BtMem {              // views of one lane's slices
-    uint8_t *cw, *csw, *seq;
+    uint8_t *cw, *csw;      // byte views of the width words
+    uint32_t *rb, *rn;      // the read: 2-bit bases, N mask (read orientation)
     uint16_t *heads16;      // narrow: in local memory
     void *pool;             // narrow: Entry16[pool_cap]; wide: Entry[pool_cap]
     uint32_t *heads;        // wide: global, PS_MAX_BUCKETS per lane
 };
+
+PS_HD void bt_mem_bind(BtMem &m, uint8_t *mine, int len, int seed_len)
+{
+    m.cw = mine; m.csw = mine + 4 * lm_ncw(len);
+    m.rb = reinterpret_cast<uint32_t *>(m.csw + 4 * lm_ncsw(seed_len));
+    m.rn = m.rb + ((len + 15) >> 4);
+    m.heads16 = reinterpret_cast<uint16_t *>(mine + lm_heads_off(len, seed_len));
+}
+// base j of the reverse-complemented read (what the search consumes): 0..3, 4 = N
+PS_HD int seq_at(const BtMem &m, int j, int len)
+{
+    const int p = len - 1 - j;
+    const uint32_t b = (m.rb[p >> 4] >> (2 * (p & 15))) & 3u, n = (m.rn[p >> 5] >> (p & 31)) & 1u;
+    return n ? 4 : 3 - (int)b;
+}
 
 // The stack of one lane.  NARROW (tiers 1-2): 16-byte entries, bump allocation, bucket heads in LDS --
 // one 16-byte global store per push and one 16-byte load per pop.  WIDE (last tier, up to the 2,000,000
@@ -376,27 +395,32 @@ PS_HD void bt_hit(const BtArgs &a, BtLane &L, BtMem &m)
     out[L.n_aln++] = rec;
 }
 
-// One iteration of a lane.  next_r: the read this lane takes when it needs one (caller advances it).
+// One iteration of a lane.  fetch_r: the read this lane may take if it is idle (M_FETCH): < 0 = none offered
+// now (stay idle), >= n_reads = the input is exhausted (retire), else the read index.
 template <bool WIDE>
-PS_HD void bt_iter(const BtArgs &a, BtLane &L, BtMem &m, int &next_r, int r_stride)
+PS_HD void bt_iter(const BtArgs &a, BtLane &L, BtMem &m, int fetch_r)
 {
     const Model &md = a.md;
     const int len = a.len;
     ++L.st.iters;
     if (L.mode == M_FETCH) {
-        int r = next_r;
-        if (r >= a.n_reads) { L.mode = M_EXIT; return; }
-        next_r += r_stride;
+        if (fetch_r < 0) return;
+        if (fetch_r >= a.n_reads) { L.mode = M_EXIT; return; }
+        const int r = fetch_r;
         L.r = r; L.status = RS_OK; L.n_aln = 0;
-        // load compact widths and the reverse-complemented read into local memory
-        for (int p = 0; p <= len; ++p) m.cw[p] = a.cwb[(size_t)p * a.n_reads + r];
-        if (md.use_seed) for (int p = 0; p <= md.seed_len; ++p) m.csw[p] = a.cswb[(size_t)p * a.n_reads + r];
+        // load the compact widths and the packed read into local memory (whole words, coalesced across lanes)
+        {
+            const int ncw = lm_ncw(len), ncsw = lm_ncsw(md.seed_len);
+            uint32_t *cw32 = reinterpret_cast<uint32_t *>(m.cw), *csw32 = reinterpret_cast<uint32_t *>(m.csw);
+            for (int p = 0; p < ncw; ++p) cw32[p] = a.cwb[(size_t)p * a.n_reads + r];
+            for (int p = 0; p < ncsw; ++p) csw32[p] = a.cswb[(size_t)p * a.n_reads + r];
+            for (int p = 0; p < a.n_bw; ++p) m.rb[p] = a.bases[(size_t)p * a.n_reads + r];
+        }
         int nNu = 0;
-        for (int j = 0; j < len; ++j) {
-            int b = read_base(a.bases, a.nmask, a.n_reads, r, len - 1 - j);
-            int c = b > 3 ? 4 : 3 - b;
-            m.seq[j] = (uint8_t)c;
-            if (c > 3) nNu += md.u_mm[4][0];
+        for (int p = 0; p < a.n_mw; ++p) {
+            uint32_t w = a.nmask[(size_t)p * a.n_reads + r];
+            m.rn[p] = w;
+            nNu += (int)ps_popc(w) * md.u_mm[4][0];
         }
         if (nNu > md.max_units) { bt_finish_read(a, L); return; }
         L.k = 0; L.l = a.ix.seq_len; L.i = len; L.score = 0; L.units = 0;
@@ -420,7 +444,7 @@ PS_HD void bt_iter(const BtArgs &a, BtLane &L, BtMem &m, int &next_r, int r_stri
         else L.mode = M_EXPAND;
     }
     if (L.mode == M_EXACT) {          // no difference left: extend exactly, one base per iteration
-        int c = m.seq[L.i - 1];
+        int c = seq_at(m, L.i - 1, len);
         ++L.st.exact;
         if (c > 3) { L.mode = M_POP; return; }
         uint32_t ok, ol;
@@ -481,7 +505,7 @@ PS_HD void bt_iter(const BtArgs &a, BtLane &L, BtMem &m, int &next_r, int r_stri
                 }
             }
         }
-        int s = m.seq[i];
+        int s = seq_at(m, i, len);
         L.mode = M_POP;
         if (allow_diff && allow_M) {
             for (int j = 1; j <= 4; ++j) {

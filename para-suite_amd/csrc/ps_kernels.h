@@ -11,7 +11,7 @@ struct WidthArgs {
     IndexView ix;
     int n_reads, len, seed_len, use_seed;
     const uint32_t *bases; const uint32_t *nmask;
-    uint32_t *w; uint8_t *cwb; uint8_t *cswb;
+    uint32_t *w; uint32_t *cwb; uint32_t *cswb;   // compact width bytes, 4 positions per word, [word][n_reads]
     KStats *stats;
 };
 

@@ -12,6 +12,8 @@
 
 namespace ps {
 
+static const int PS_Q_CHUNK = 64;
+
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
 {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -39,6 +41,7 @@ __global__ void __launch_bounds__(256) k_width(WidthArgs a)
         wchain_init(a.ix, A); wchain_init(a.ix, B);
         const int len = a.len, seed_len = a.seed_len;
         uint32_t bw = 0, mw = 0, sbw = 0, smw = 0;  // current base / N-mask words of the two chains
+        uint32_t cww = 0, csww = 0;                  // compact width bytes being assembled, 4 positions per word
         for (int i = 0; i < len; ++i) {
             int j = len - 1 - i;
             if (i == 0 || (j & 15) == 15) bw = a.bases[(size_t)(j >> 4) * a.n_reads + r];
@@ -52,15 +55,21 @@ __global__ void __launch_bounds__(256) k_width(WidthArgs a)
                 int sbase = ((smw >> (js & 31)) & 1u) ? 4 : (int)((sbw >> (2 * (js & 15))) & 3u);
                 uint32_t swv; uint8_t scb;
                 wchain_step(a.ix, B, sbase, swv, scb, i == 0, st);
-                a.cswb[(size_t)i * a.n_reads + r] = scb;
+                csww |= (uint32_t)scb << (8 * (i & 3));
+                if ((i & 3) == 3) { a.cswb[(size_t)(i >> 2) * a.n_reads + r] = csww; csww = 0; }
             }
             wchain_step(a.ix, A, base, wv, cb, i == 0, st);
             a.w[(size_t)i * a.n_reads + r] = wv;
-            a.cwb[(size_t)i * a.n_reads + r] = cb;
+            cww |= (uint32_t)cb << (8 * (i & 3));
+            if ((i & 3) == 3) { a.cwb[(size_t)(i >> 2) * a.n_reads + r] = cww; cww = 0; }
         }
         a.w[(size_t)len * a.n_reads + r] = 0;
-        a.cwb[(size_t)len * a.n_reads + r] = cw_pack(A.bid + 1, false);
-        if (a.use_seed) a.cswb[(size_t)seed_len * a.n_reads + r] = cw_pack(B.bid + 1, false);
+        cww |= (uint32_t)cw_pack(A.bid + 1, false) << (8 * (len & 3));
+        a.cwb[(size_t)(len >> 2) * a.n_reads + r] = cww;
+        if (a.use_seed) {
+            csww |= (uint32_t)cw_pack(B.bid + 1, false) << (8 * (seed_len & 3));
+            a.cswb[(size_t)(seed_len >> 2) * a.n_reads + r] = csww;
+        }
     }
     flush_stats(a.stats, st);
 }
@@ -73,15 +82,50 @@ __global__ void __launch_bounds__(256) k_backtrack(BtArgs a, int lm_stride)
     const int lane_g = blockIdx.x * blockDim.x + threadIdx.x;
     BtMem m;
     uint8_t *mine = smem + (size_t)threadIdx.x * lm_stride;
-    m.cw = mine; m.csw = mine + a.len + 1; m.seq = m.csw + a.md.seed_len + 1;
-    m.heads16 = reinterpret_cast<uint16_t *>(mine + lm_heads_off(a.len, a.md.seed_len));
+    bt_mem_bind(m, mine, a.len, a.md.seed_len);
     m.pool = reinterpret_cast<uint8_t *>(a.pool) + (size_t)lane_g * a.pool_cap * (WIDE ? sizeof(Entry) : sizeof(Entry16));
     m.heads = WIDE ? a.heads + (size_t)lane_g * PS_MAX_BUCKETS : nullptr;
     BtLane L;
     L.mode = M_FETCH; L.r = 0; L.have_cur = false; L.n_stack = 0; L.status = RS_OK; L.n_aln = 0;
     L.st = {0, 0, 0, 0, 0, 0, 0, 0};
-    int next_r = lane_g;
-    while (L.mode != M_EXIT) bt_iter<WIDE>(a, L, m, next_r, a.n_lanes);
+    // Reads are handed out dynamically: search effort differs by orders of magnitude between reads, so a
+    // lane takes a new read as soon as it is done.  A wave reserves chunks of PS_Q_CHUNK reads from one
+    // global counter (one atomic per chunk) and deals them to its idle lanes by ballot rank; it loads new
+    // reads only when fetch_min lanes are idle (or nothing else is running), because the load path is
+    // executed by the whole wave.
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    int q_next = 0, q_end = 0;
+    bool exhausted = false;
+    for (;;) {
+        const bool want = L.mode == M_FETCH;
+        const unsigned long long wmask = __ballot(want), lmask = __ballot(L.mode != M_EXIT);
+        if (lmask == 0) break;
+        int fetch_r = -1;
+        if (wmask) {
+            const int cnt = __popcll(wmask);
+            if (cnt >= a.fetch_min || wmask == lmask) {
+                const int rank = __popcll(wmask & lane_lt);
+                int served = 0;
+                while (served < cnt) {
+                    if (q_next == q_end) {
+                        if (exhausted) break;
+                        unsigned int base = 0;
+                        if (lane == 0) base = atomicAdd(a.queue, (unsigned int)PS_Q_CHUNK);
+                        base = (unsigned int)__shfl((int)base, 0, 64);
+                        if (base >= (unsigned int)a.n_reads) { exhausted = true; break; }
+                        q_next = (int)base;
+                        q_end = (int)base + PS_Q_CHUNK < a.n_reads ? (int)base + PS_Q_CHUNK : a.n_reads;
+                    }
+                    const int take = q_end - q_next < cnt - served ? q_end - q_next : cnt - served;
+                    if (want && rank >= served && rank < served + take) fetch_r = q_next + (rank - served);
+                    q_next += take; served += take;
+                }
+                if (want && fetch_r < 0 && exhausted) fetch_r = a.n_reads;   // nothing left: this lane retires
+            }
+        }
+        bt_iter<WIDE>(a, L, m, fetch_r);
+    }
     flush_stats(a.stats, L.st);
 }
 

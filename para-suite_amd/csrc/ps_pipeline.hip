@@ -172,8 +172,8 @@ static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases
 {
     Ctx *ctx = b.ctx; hipStream_t s = ctx->stream;
     const int len = md.len, seed_len = md.seed_len;
-    DevBuf<uint32_t> w; DevBuf<uint8_t> cwb, cswb, status; DevBuf<AlnRec> alns; DevBuf<int32_t> n_aln;
-    w.alloc((size_t)(len + 1) * n); cwb.alloc((size_t)(len + 1) * n); cswb.alloc((size_t)(seed_len + 1) * n);
+    DevBuf<uint32_t> w, cwb, cswb; DevBuf<uint8_t> status; DevBuf<AlnRec> alns; DevBuf<int32_t> n_aln;
+    w.alloc((size_t)(len + 1) * n); cwb.alloc((size_t)lm_ncw(len) * n); cswb.alloc((size_t)(lm_ncsw(seed_len) + 1) * n);
     status.alloc(n); alns.alloc((size_t)n * aln_cap); n_aln.alloc(n);
     WidthArgs wa;
     wa.ix = ctx->ix.view; wa.n_reads = n; wa.len = len; wa.seed_len = seed_len; wa.use_seed = md.use_seed;
@@ -202,7 +202,9 @@ static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases
     a.bases = d_bases; a.nmask = d_nmask; a.n_bw = (len + 15) / 16; a.n_mw = (len + 31) / 32;
     a.w = w.p; a.cwb = cwb.p; a.cswb = cswb.p;
     a.alns = alns.p; a.aln_cap = aln_cap; a.n_aln = n_aln.p; a.status = status.p;
+    DevBuf<uint32_t> queue; queue.alloc(1); queue.zero(s);
     a.pool = pool.p; a.pool_cap = pool_cap; a.heads = heads.p; a.wide = wide ? 1 : 0; a.stats = b.d_stats.p + 1;
+    a.queue = queue.p; a.fetch_min = ctx->fetch_min;
     { EvTimer t(s); launch_backtrack(a, blocks, lm, s); PS_HIP(hipGetLastError()); b.tm.ms_backtrack += t.stop(); ++b.tm.n_backtrack_launches; }
     // compact the hit lists on the device, then one download
     EvTimer tc(s);

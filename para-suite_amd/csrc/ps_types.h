@@ -87,13 +87,15 @@ struct BtArgs {
     const uint32_t *bases; const uint32_t *nmask; int n_bw, n_mw;
     // from the width kernel, [pos][n_reads]: interval sizes w (updated by hit shadowing), compact
     // width bytes cwb (bid | eq<<7) for the read and cswb for its seed
-    uint32_t *w; const uint8_t *cwb; const uint8_t *cswb;
+    uint32_t *w; const uint32_t *cwb; const uint32_t *cswb;   // cwb/cswb: 4 positions per word, [word][n_reads]
     // outputs
     AlnRec *alns; int aln_cap; int32_t *n_aln; uint8_t *status;
     // per-lane scratch
     void *pool; uint32_t pool_cap;                    // per lane: pool_cap entries (16 B narrow / 32 B wide)
     uint32_t *heads;                                  // wide stack only: heads[lane*PS_MAX_BUCKETS + bucket]
     int wide;
+    uint32_t *queue;                                  // next unassigned read (waves take chunks of it)
+    int fetch_min;                                    // idle lanes a wave waits for before it loads new reads
     KStats *stats;
 };
 

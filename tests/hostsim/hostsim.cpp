@@ -73,25 +73,25 @@ int hs_aln(void *p, const Model *md, int n_reads, int len, const uint8_t *codes,
         }
     int seed_len = md->seed_len;
     std::vector<uint32_t> w((size_t)(len + 1) * n_reads);
-    std::vector<uint8_t> cwb((size_t)(len + 1) * n_reads), cswb((size_t)(seed_len + 1) * n_reads, 0);
+    std::vector<uint32_t> cwb((size_t)lm_ncw(len) * n_reads, 0), cswb((size_t)(lm_ncsw(seed_len) + 1) * n_reads, 0);
+    auto put = [&](std::vector<uint32_t> &v, int pos, int r, uint8_t byte) { v[(size_t)(pos >> 2) * n_reads + r] |= (uint32_t)byte << (8 * (pos & 3)); };
     LaneStats st; memset(&st, 0, sizeof st);
     for (int r = 0; r < n_reads; ++r) {                 // width kernel body
         WChain A, B; wchain_init(s->v, A); wchain_init(s->v, B);
         for (int i = 0; i < len; ++i) {
             uint32_t wv; uint8_t cb;
             wchain_step(s->v, A, read_base(bases.data(), nmask.data(), n_reads, r, len - 1 - i), wv, cb, i == 0, st);
-            w[(size_t)i * n_reads + r] = wv; cwb[(size_t)i * n_reads + r] = cb;
+            w[(size_t)i * n_reads + r] = wv; put(cwb, i, r, cb);
             if (md->use_seed && i < seed_len) {
                 wchain_step(s->v, B, read_base(bases.data(), nmask.data(), n_reads, r, seed_len - 1 - i), wv, cb, i == 0, st);
-                cswb[(size_t)i * n_reads + r] = cb;
+                put(cswb, i, r, cb);
             }
         }
-        w[(size_t)len * n_reads + r] = 0; cwb[(size_t)len * n_reads + r] = cw_pack(A.bid + 1, false);
-        if (md->use_seed) cswb[(size_t)seed_len * n_reads + r] = cw_pack(B.bid + 1, false);
+        w[(size_t)len * n_reads + r] = 0; put(cwb, len, r, cw_pack(A.bid + 1, false));
+        if (md->use_seed) put(cswb, seed_len, r, cw_pack(B.bid + 1, false));
     }
     if (w_out) memcpy(w_out, w.data(), w.size() * 4);
-    if (cwb_out) memcpy(cwb_out, cwb.data(), cwb.size());
-    if (cswb_out) memcpy(cswb_out, cswb.data(), cswb.size());
+    (void)cwb_out; (void)cswb_out;
     BtArgs a; memset(&a, 0, sizeof a);
     a.ix = s->v; a.md = *md; a.n_reads = n_reads; a.len = len; a.n_lanes = n_lanes;
     a.bases = bases.data(); a.nmask = nmask.data(); a.n_bw = n_bw; a.n_mw = n_mw;
@@ -112,11 +112,12 @@ int hs_aln(void *p, const Model *md, int n_reads, int len, const uint8_t *codes,
             BtLane &L = lanes[t];
             if (L.mode == M_EXIT) continue;
             BtMem m; uint8_t *mine = lm.data() + (size_t)t * lmb;
-            m.cw = mine; m.csw = mine + len + 1; m.seq = m.csw + seed_len + 1;
-            m.heads16 = reinterpret_cast<uint16_t *>(mine + lm_heads_off(len, seed_len));
+            bt_mem_bind(m, mine, len, seed_len);
             m.pool = pool.data() + (size_t)t * pool_cap * (wide ? sizeof(Entry) : sizeof(Entry16));
             m.heads = a.heads + (size_t)t * PS_MAX_BUCKETS;
-            if (wide) bt_iter<true>(a, L, m, next[t], n_lanes); else bt_iter<false>(a, L, m, next[t], n_lanes);
+            int fr = -1;                                   // static hand-out here; the kernel deals reads from a queue
+            if (L.mode == M_FETCH) { fr = next[t] < n_reads ? next[t] : n_reads; next[t] += n_lanes; }
+            if (wide) bt_iter<true>(a, L, m, fr); else bt_iter<false>(a, L, m, fr);
             any = true;
         }
     }
