@@ -90,6 +90,7 @@ int     ps_batch_n_aln(ps_batch *, int32_t *out, int64_t cap);       /* per read
 int64_t ps_batch_alns(ps_batch *, int64_t read, ps_aln *out, int64_t cap);
 int     ps_batch_hits(ps_batch *, ps_hit *out, int64_t cap);
 int     ps_batch_timing(ps_batch *, ps_timing *out);
+int64_t ps_ctx_read_iters(ps_ctx *, uint32_t *out, int64_t cap);   /* profiling aid (env PS_READ_ITERS=1): iterations per read of the last search launch */
 int     ps_batch_kstats(ps_batch *, int which /*0 width 1 backtrack 2 sa2pos*/, ps_kstats *out);
 
 #ifdef __cplusplus

@@ -42,7 +42,7 @@ EXPORTS = ["ps_version", "ps_last_error", "ps_index", "ps_map", "ps_ctx_open", "
            "ps_ctx_blob", "ps_ctx_meta", "ps_ctx_from_blobs", "ps_ctx_fetch", "ps_ctx_export_blob", "ps_batch_from_fastq",
            "ps_batch_from_codes", "ps_batch_free", "ps_batch_n", "ps_batch_search", "ps_batch_select_hard",
            "ps_batch_select_easy", "ps_batch_locate", "ps_batch_run", "ps_batch_write_sam", "ps_batch_n_aln",
-           "ps_batch_alns", "ps_batch_hits", "ps_batch_timing", "ps_batch_kstats"]
+           "ps_batch_alns", "ps_batch_hits", "ps_batch_timing", "ps_batch_kstats", "ps_ctx_read_iters"]
 
 _LIB = None
 
@@ -94,6 +94,8 @@ def lib():
     L.ps_batch_alns.restype = C.c_int64
     L.ps_batch_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     L.ps_batch_timing.argtypes = [C.c_void_p, P(Timing)]
+    L.ps_ctx_read_iters.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    L.ps_ctx_read_iters.restype = C.c_int64
     L.ps_batch_kstats.argtypes = [C.c_void_p, C.c_int, P(KStats)]
     _LIB = L
     return L
@@ -188,20 +190,23 @@ class Ctx:
         info = self.info()
         blk = self.fetch(0).view("<u4").reshape(-1, 16)
         out = np.empty(blk.shape[0] * 192, dtype=np.uint8)
-        sh = (np.arange(16, dtype=np.uint32) * 2)[None, None, :]
+        sh = np.arange(32, dtype=np.uint32)[None, None, :]
         for a in range(0, blk.shape[0], chunk_blocks):
-            w = blk[a:a + chunk_blocks, 4:]
-            out[a * 192:(a + w.shape[0]) * 192] = ((w[:, :, None] >> sh) & 3).astype(np.uint8).reshape(-1)
+            lo = (blk[a:a + chunk_blocks, 4:10, None] >> sh) & 1
+            hi = (blk[a:a + chunk_blocks, 10:16, None] >> sh) & 1
+            out[a * 192:(a + lo.shape[0]) * 192] = (lo | (hi << 1)).astype(np.uint8).reshape(-1)
         return out[:info.seq_len]
 
     def bwt_syms(self):
-        """Decode the Occ blocks back into the BWT symbol string (tests: compare with the oracle's BWT)."""
-        info = self.info()
+        """Decode the Occ blocks (two bit planes per block) back into the BWT symbol string; also the block counts."""
         blk = self.fetch(0).view("<u4").reshape(-1, 16)
-        words = blk[:, 4:]
-        sh = (np.arange(16, dtype=np.uint32) * 2)[None, None, :]
-        syms = ((words[:, :, None] >> sh) & 3).astype(np.uint8).reshape(-1)
-        return syms[:info.seq_len], blk[:, :4]
+        return self.bwt_syms_chunked(), blk[:, :4]
+
+    def read_iters(self):
+        n = lib().ps_ctx_read_iters(self.h, None, 0)
+        out = np.zeros(n, dtype=np.uint32)
+        lib().ps_ctx_read_iters(self.h, out.ctypes.data, n)
+        return out
 
     def batch_from_fastq(self, path):
         return Batch(lib().ps_batch_from_fastq(self.h, path.encode()), self)

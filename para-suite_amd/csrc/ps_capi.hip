@@ -32,6 +32,7 @@ static ps_ctx *new_ctx(int device)
     x->c.device = device;
     PS_HIP(hipStreamCreateWithFlags(&x->c.stream, hipStreamNonBlocking));
     if (const char *e = std::getenv("PS_FETCH_MIN")) x->c.fetch_min = std::atoi(e);       // tuning knobs
+    if (std::getenv("PS_READ_ITERS")) x->c.want_read_iters = true;
     if (const char *e = std::getenv("PS_BT_BLOCKS")) x->c.bt_blocks = std::atoi(e);
     if (const char *e = std::getenv("PS_POOL_CAP")) x->c.pool_cap[0] = (uint32_t)std::atoi(e);
     return x;
@@ -236,6 +237,12 @@ int ps_batch_hits(ps_batch *b, ps_hit *out, int64_t cap)
         }
         return 0;
     PS_CATCH_INT
+}
+int64_t ps_ctx_read_iters(ps_ctx *x, uint32_t *out, int64_t cap)
+{
+    const int64_t n = (int64_t)x->c.read_iters.size();
+    for (int64_t i = 0; i < n && i < cap; ++i) out[i] = x->c.read_iters[i];
+    return n;
 }
 int ps_batch_timing(ps_batch *b, ps_timing *o)
 {

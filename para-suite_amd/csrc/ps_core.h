@@ -24,12 +24,12 @@ PS_HD uint32_t ps_popc(uint32_t x)
     return (uint32_t)__builtin_popcount(x);
 #endif
 }
-PS_HD uint32_t pfx_mask(int ns) // low-bit-of-pair mask covering the first ns symbols of a word
+PS_HD uint32_t pfx_mask32(int ns) // mask of the first ns (<=32) symbols of a 32-symbol plane word
 {
-    return ns >= 16 ? 0x55555555u : (ns <= 0 ? 0u : (((1u << (2 * ns)) - 1u) & 0x55555555u));
+    return ns >= 32 ? 0xFFFFFFFFu : (ns <= 0 ? 0u : ((1u << ns) - 1u));
 }
 
-struct Blk { uint32_t x[16]; };  // cnt[4] + sym[12]
+struct Blk { uint32_t x[16]; };  // cnt[4] + lo[6] + hi[6]
 
 PS_HD void load_blk(const OccBlock *blocks, uint32_t b, Blk &o)
 {
@@ -46,14 +46,15 @@ PS_HD void load_blk(const OccBlock *blocks, uint32_t b, Blk &o)
 #endif
 }
 
-// occurrences of every symbol among the first r (1..192) symbols of the block, plus the block base
+// occurrences of every symbol among the first r (1..192) symbols of the block, plus the block base.
+// The symbols are stored as two bit planes (lo = x[4..9], hi = x[10..15], 32 symbols per word), so one
+// prefix mask and three popcounts per 32 symbols give all four counts.
 PS_HD void blk_count4(const Blk &b, int r, uint32_t cnt[4])
 {
     uint32_t c1 = 0, c2 = 0, c3 = 0;
 #pragma unroll
-    for (int j = 0; j < 12; ++j) {
-        uint32_t w = b.x[4 + j], m = pfx_mask(r - 16 * j);
-        uint32_t lo = w & m, hi = (w >> 1) & m;
+    for (int j = 0; j < 6; ++j) {
+        const uint32_t m = pfx_mask32(r - 32 * j), lo = b.x[4 + j] & m, hi = b.x[10 + j] & m;
         c3 += ps_popc(lo & hi);
         c2 += ps_popc(hi & ~lo);
         c1 += ps_popc(lo & ~hi);
@@ -63,32 +64,40 @@ PS_HD void blk_count4(const Blk &b, int r, uint32_t cnt[4])
 }
 PS_HD uint32_t blk_count1(const Blk &b, int r, int c)
 {
-    uint32_t n = 0, pat = 0x55555555u * (uint32_t)(3 - c); // XOR makes symbol c read 11
+    uint32_t n = 0;
+    const uint32_t flo = (c & 1) ? 0u : 0xFFFFFFFFu, fhi = (c & 2) ? 0u : 0xFFFFFFFFu;   // XOR masks: symbol c reads 1,1
 #pragma unroll
-    for (int j = 0; j < 12; ++j) {
-        uint32_t w = b.x[4 + j] ^ pat, m = pfx_mask(r - 16 * j);
-        n += ps_popc(w & (w >> 1) & m);
-    }
+    for (int j = 0; j < 6; ++j) n += ps_popc((b.x[4 + j] ^ flo) & (b.x[10 + j] ^ fhi) & pfx_mask32(r - 32 * j));
     uint32_t base = c == 0 ? b.x[0] : (c == 1 ? b.x[1] : (c == 2 ? b.x[2] : b.x[3]));
     return base + n;
 }
 PS_HD int blk_sym(const Blk &b, int pos) // symbol pos (0..191) of the block
 {
-    uint32_t w = 0; int wi = pos >> 4;
+    uint32_t lo = 0, hi = 0; const int wi = pos >> 5;
 #pragma unroll
-    for (int j = 0; j < 12; ++j) w = (j == wi) ? b.x[4 + j] : w;
-    return (int)((w >> (2 * (pos & 15))) & 3u);
+    for (int j = 0; j < 6; ++j) { lo = (j == wi) ? b.x[4 + j] : lo; hi = (j == wi) ? b.x[10 + j] : hi; }
+    return (int)(((lo >> (pos & 31)) & 1u) | (((hi >> (pos & 31)) & 1u) << 1));
 }
 
 // build one block from up to 192 symbols (codes 0..3) and the running counts before it
 PS_HD void blk_pack(OccBlock &b, const uint8_t *syms, int n, const uint32_t cnt[4])
 {
     for (int c = 0; c < 4; ++c) b.cnt[c] = cnt[c];
-    for (int j = 0; j < 12; ++j) {
-        uint32_t w = 0;
-        for (int t = 0; t < 16; ++t) { int p = j * 16 + t; if (p < n) w |= (uint32_t)(syms[p] & 3) << (2 * t); }
-        b.sym[j] = w;
+    for (int j = 0; j < 6; ++j) {
+        uint32_t lo = 0, hi = 0;
+        for (int t = 0; t < 32; ++t) { int p = j * 32 + t; if (p < n) { lo |= (uint32_t)(syms[p] & 1) << t; hi |= (uint32_t)((syms[p] >> 1) & 1) << t; } }
+        b.sym[j] = lo; b.sym[6 + j] = hi;
     }
+}
+
+// register-only selects (dynamic indexing of small arrays would push them to scratch memory)
+PS_HD uint32_t sel4(const uint32_t v[4], int c) { return c == 0 ? v[0] : (c == 1 ? v[1] : (c == 2 ? v[2] : v[3])); }
+PS_HD bwtint L2_of(const IndexView &ix, int c) { return c == 0 ? ix.L2[0] : (c == 1 ? ix.L2[1] : (c == 2 ? ix.L2[2] : ix.L2[3])); }
+// cost of reading text symbol c where the (reverse-complemented) read has s: four byte lanes per read symbol
+PS_HD int cost_of(const uint32_t pk[5], int s, int c)
+{
+    const uint32_t w = s == 0 ? pk[0] : (s == 1 ? pk[1] : (s == 2 ? pk[2] : (s == 3 ? pk[3] : pk[4])));
+    return (int)((w >> (8 * c)) & 0xffu);
 }
 
 // row (0..n) of the BW matrix of T$ -> index into the stored BWT (the '$' row is not stored)
@@ -155,8 +164,9 @@ PS_HD void wchain_step(const IndexView &ix, WChain &c, int base, uint32_t &w_out
     if (base < 4) {
         uint32_t ok, ol;
         occ_pair1(ix, c.k, c.l, base, ok, ol, st);
-        c.k = ix.L2[base] + ok + 1;
-        c.l = ix.L2[base] + ol;
+        const bwtint l2 = L2_of(ix, base);
+        c.k = l2 + ok + 1;
+        c.l = l2 + ol;
     }
     if (c.k > c.l || base > 3) { c.k = 0; c.l = ix.seq_len; ++c.bid; }
     uint32_t w = c.l - c.k + 1;
@@ -176,8 +186,8 @@ struct BtLane {
     bool have_cur;
     int best_score, max_units, n_aln, n_stack, status;
     unsigned long long best_cnt;
-    unsigned long long bm[2];  // non-empty score buckets
-    uint32_t bump, free_head;
+    unsigned long long bm0, bm1;  // non-empty score buckets (two scalars: a dynamically indexed array would live in scratch)
+    uint32_t bump, free_head, iters0;
     LaneStats st;
 };
 
@@ -225,18 +235,17 @@ PS_HD int seq_at(const BtMem &m, int j, int len)
 struct Entry16 { uint32_t k, l, a, b; };
 static const uint32_t PS_NIL16 = 0xFFFFu;
 
-PS_HD bool bm_test(const BtLane &L, int b) { return (L.bm[b >> 6] >> (b & 63)) & 1ull; }
-PS_HD void bm_set(BtLane &L, int b) { L.bm[b >> 6] |= 1ull << (b & 63); }
-PS_HD void bm_clr(BtLane &L, int b) { L.bm[b >> 6] &= ~(1ull << (b & 63)); }
+PS_HD bool bm_test(const BtLane &L, int b) { return (((b & 64) ? L.bm1 : L.bm0) >> (b & 63)) & 1ull; }
+PS_HD void bm_set(BtLane &L, int b) { const unsigned long long v = 1ull << (b & 63); if (b & 64) L.bm1 |= v; else L.bm0 |= v; }
+PS_HD void bm_clr(BtLane &L, int b) { const unsigned long long v = ~(1ull << (b & 63)); if (b & 64) L.bm1 &= v; else L.bm0 &= v; }
 PS_HD int bm_first(const BtLane &L)
 {
 #ifdef __HIP_DEVICE_COMPILE__
-    return L.bm[0] ? (__ffsll((unsigned long long)L.bm[0]) - 1) : (64 + __ffsll((unsigned long long)L.bm[1]) - 1);
+    return L.bm0 ? (__ffsll((unsigned long long)L.bm0) - 1) : (64 + __ffsll((unsigned long long)L.bm1) - 1);
 #else
-    return L.bm[0] ? __builtin_ctzll(L.bm[0]) : 64 + __builtin_ctzll(L.bm[1]);
+    return L.bm0 ? __builtin_ctzll(L.bm0) : 64 + __builtin_ctzll(L.bm1);
 #endif
 }
-
 PS_HD void store16(Entry16 *dst, const Entry16 &e)
 {
 #ifdef __HIP_DEVICE_COMPILE__
@@ -348,6 +357,7 @@ PS_HD void bt_finish_read(const BtArgs &a, BtLane &L)
 {
     a.n_aln[L.r] = L.n_aln;
     a.status[L.r] = (uint8_t)L.status;
+    if (a.read_iters) a.read_iters[L.r] = L.st.iters - L.iters0;
     L.mode = M_FETCH;
 }
 
@@ -407,7 +417,7 @@ PS_HD void bt_iter(const BtArgs &a, BtLane &L, BtMem &m, int fetch_r)
         if (fetch_r < 0) return;
         if (fetch_r >= a.n_reads) { L.mode = M_EXIT; return; }
         const int r = fetch_r;
-        L.r = r; L.status = RS_OK; L.n_aln = 0;
+        L.r = r; L.status = RS_OK; L.n_aln = 0; L.iters0 = L.st.iters;
         // load the compact widths and the packed read into local memory (whole words, coalesced across lanes)
         {
             const int ncw = lm_ncw(len), ncsw = lm_ncsw(md.seed_len);
@@ -420,12 +430,12 @@ PS_HD void bt_iter(const BtArgs &a, BtLane &L, BtMem &m, int fetch_r)
         for (int p = 0; p < a.n_mw; ++p) {
             uint32_t w = a.nmask[(size_t)p * a.n_reads + r];
             m.rn[p] = w;
-            nNu += (int)ps_popc(w) * md.u_mm[4][0];
+            nNu += (int)ps_popc(w) * (int)(md.u_mm_pk[4] & 0xffu);
         }
         if (nNu > md.max_units) { bt_finish_read(a, L); return; }
         L.k = 0; L.l = a.ix.seq_len; L.i = len; L.score = 0; L.units = 0;
         L.n_mm = L.n_gapo = L.n_gape = L.n_ins = L.n_del = 0; L.state = ST_M; L.ldp = 0;
-        L.have_cur = true; L.n_stack = 0; L.bm[0] = L.bm[1] = 0; L.bump = 0; L.free_head = PS_NIL;
+        L.have_cur = true; L.n_stack = 0; L.bm0 = L.bm1 = 0; L.bump = 0; L.free_head = PS_NIL;
         L.best_score = 1 << 29; L.max_units = md.max_units; L.best_cnt = 0;
         L.mode = M_POP;
     }
@@ -437,33 +447,36 @@ PS_HD void bt_iter(const BtArgs &a, BtLane &L, BtMem &m, int fetch_r)
         if (L.score > L.best_score + md.s_stop) { bt_finish_read(a, L); return; }
         int rem = L.max_units - L.units;
         if (rem < 0) return;
-        int mleft = md.c_min == 1 ? rem : rem / md.c_min;
+        const int mleft = (int)(((uint32_t)rem * (uint32_t)md.inv_c_min) >> 16);     // rem / c_min
         if (L.i > 0 && mleft < (int)(m.cw[L.i - 1] & 0x7f)) return;
         if (L.i == 0) { bt_hit(a, L, m); return; }
         if (mleft == 0 && (L.state == ST_M || md.mode_gape || L.n_gape == md.max_gape)) L.mode = M_EXACT;
         else L.mode = M_EXPAND;
     }
+    // ---- the memory step, shared by both search modes: Occ(k-1,.) and Occ(l,.) -> the four child intervals ----
+    uint32_t ck[4], cl[4];
+    occ_pair4(a.ix, L.k, L.l, ck, cl, L.st);
+    bwtint nk[4], nl[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { nk[c] = a.ix.L2[c] + ck[c] + 1; nl[c] = a.ix.L2[c] + cl[c]; }
     if (L.mode == M_EXACT) {          // no difference left: extend exactly, one base per iteration
-        int c = seq_at(m, L.i - 1, len);
+        const int c = seq_at(m, L.i - 1, len);
         ++L.st.exact;
         if (c > 3) { L.mode = M_POP; return; }
-        uint32_t ok, ol;
-        occ_pair1(a.ix, L.k, L.l, c, ok, ol, L.st);
-        bwtint nk = a.ix.L2[c] + ok + 1, nl = a.ix.L2[c] + ol;
-        if (nk > nl) { L.mode = M_POP; return; }
-        L.k = nk; L.l = nl; --L.i;
+        const bwtint k2 = sel4(nk, c), l2 = sel4(nl, c);
+        if (k2 > l2) { L.mode = M_POP; return; }
+        L.k = k2; L.l = l2; --L.i;
         if (L.i == 0) { L.mode = M_POP; bt_hit(a, L, m); }
         return;
     }
-    if (L.mode == M_EXPAND) {
-        int i = L.i - 1;
-        uint32_t ck[4], cl[4];
+    {
+        const int i = L.i - 1;
         ++L.st.nodes;
-        occ_pair4(a.ix, L.k, L.l, ck, cl, L.st);
-        bwtint occ = L.l - L.k + 1;
-        int rem = L.max_units - L.units;
-        int mleft = md.c_min == 1 ? rem : rem / md.c_min;
-        int m_seed = (md.max_seed_diff * md.u_tight - L.units) / md.c_min;   // seed budget, in units like the read budget
+        const bwtint occ = L.l - L.k + 1;
+        const int rem = L.max_units - L.units;
+        const int mleft = (int)(((uint32_t)rem * (uint32_t)md.inv_c_min) >> 16);
+        const int srem = md.max_seed_diff * md.u_tight - L.units;                  // seed budget, in units like the read budget
+        const int m_seed = srem <= 0 ? 0 : (int)(((uint32_t)srem * (uint32_t)md.inv_c_min) >> 16);
         bool allow_diff = true, allow_M = true;
         if (i > 0) {
             int b1 = m.cw[i - 1] & 0x7f, b0 = m.cw[i] & 0x7f;
@@ -483,46 +496,44 @@ PS_HD void bt_iter(const BtArgs &a, BtLane &L, BtMem &m, int fetch_r)
         const int e_mm = L.n_mm, e_go = L.n_gapo, e_ge = L.n_gape, e_ni = L.n_ins, e_nd = L.n_del;
         const int e_sc = L.score, e_un = L.units, e_st = L.state;
         const bwtint ek = L.k, el = L.l;
-        int tmp = e_go + e_ge;
+        const int tmp = e_go + e_ge;
         if (allow_diff && i >= md.indel_end_skip + tmp && len - i >= md.indel_end_skip + tmp) {
             if (e_st == ST_M) {
                 if (e_go < md.max_gapo) {
                     bt_push<WIDE>(a, L, m, i, ek, el, e_mm, e_go + 1, e_ge, e_ni + 1, e_nd, ST_I, true, e_sc + md.s_gapo_ins, e_un + md.u_gapo_ins);
-                    for (int j = 0; j < 4; ++j) {
-                        bwtint nk = a.ix.L2[j] + ck[j] + 1, nl = a.ix.L2[j] + cl[j];
-                        if (nk <= nl) bt_push<WIDE>(a, L, m, i + 1, nk, nl, e_mm, e_go + 1, e_ge, e_ni, e_nd + 1, ST_D, true, e_sc + md.s_gapo_del, e_un + md.u_gapo_del);
-                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (nk[j] <= nl[j]) bt_push<WIDE>(a, L, m, i + 1, nk[j], nl[j], e_mm, e_go + 1, e_ge, e_ni, e_nd + 1, ST_D, true, e_sc + md.s_gapo_del, e_un + md.u_gapo_del);
                 }
             } else if (e_st == ST_I) {
                 if (e_ge < md.max_gape)
                     bt_push<WIDE>(a, L, m, i, ek, el, e_mm, e_go, e_ge + 1, e_ni + 1, e_nd, ST_I, true, e_sc + md.s_gape, e_un + md.u_gape);
             } else {
                 if (e_ge < md.max_gape && ((e_ge + e_go) * md.u_tight < L.max_units || occ < (bwtint)md.max_del_occ)) {
-                    for (int j = 0; j < 4; ++j) {
-                        bwtint nk = a.ix.L2[j] + ck[j] + 1, nl = a.ix.L2[j] + cl[j];
-                        if (nk <= nl) bt_push<WIDE>(a, L, m, i + 1, nk, nl, e_mm, e_go, e_ge + 1, e_ni, e_nd + 1, ST_D, true, e_sc + md.s_gape, e_un + md.u_gape);
-                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (nk[j] <= nl[j]) bt_push<WIDE>(a, L, m, i + 1, nk[j], nl[j], e_mm, e_go, e_ge + 1, e_ni, e_nd + 1, ST_D, true, e_sc + md.s_gape, e_un + md.u_gape);
                 }
             }
         }
-        int s = seq_at(m, i, len);
+        const int s = seq_at(m, i, len);
         L.mode = M_POP;
         if (allow_diff && allow_M) {
+#pragma unroll
             for (int j = 1; j <= 4; ++j) {
-                int c = (s + j) & 3;
-                bool is_mm = (j != 4 || s > 3);
-                bwtint nk = a.ix.L2[c] + ck[c] + 1, nl = a.ix.L2[c] + cl[c];
-                if (nk > nl) continue;
-                if (is_mm) bt_push<WIDE>(a, L, m, i, nk, nl, e_mm + 1, e_go, e_ge, e_ni, e_nd, ST_M, true, e_sc + md.s_mm[s][c], e_un + md.u_mm[s][c]);
+                const int c = (s + j) & 3;
+                const bool is_mm = (j != 4 || s > 3);
+                const bwtint k2 = sel4(nk, c), l2 = sel4(nl, c);
+                if (k2 > l2) continue;
+                if (is_mm) bt_push<WIDE>(a, L, m, i, k2, l2, e_mm + 1, e_go, e_ge, e_ni, e_nd, ST_M, true, e_sc + cost_of(md.s_mm_pk, s, c), e_un + cost_of(md.u_mm_pk, s, c));
                 else { // the match child has the parent's score and is pushed last: it is the next pop
-                    L.k = nk; L.l = nl; L.i = i; L.state = ST_M; L.ldp = 0; L.have_cur = true;
+                    L.k = k2; L.l = l2; L.i = i; L.state = ST_M; L.ldp = 0; L.have_cur = true;
                 }
             }
         } else if (s < 4) {
-            bwtint nk = a.ix.L2[s] + ck[s] + 1, nl = a.ix.L2[s] + cl[s];
-            if (nk <= nl) { L.k = nk; L.l = nl; L.i = i; L.state = ST_M; L.ldp = 0; L.have_cur = true; }
+            const bwtint k2 = sel4(nk, s), l2 = sel4(nl, s);
+            if (k2 <= l2) { L.k = k2; L.l = l2; L.i = i; L.state = ST_M; L.ldp = 0; L.have_cur = true; }
         }
-        return;
     }
 }
 
@@ -538,7 +549,7 @@ PS_HD bool sa_walk_step(const IndexView &ix, bwtint &row, uint32_t &steps, LaneS
     Blk x;
     load_blk(ix.blocks, b, x);
     int c = blk_sym(x, pos);
-    row = ix.L2[c] + blk_count1(x, pos + 1, c);
+    row = L2_of(ix, c) + blk_count1(x, pos + 1, c);
     return true;
 }
 

@@ -163,6 +163,11 @@ inline bool make_model(const Options &o, int len, Model &m, std::string &err)
         m.max_units = budget_diffs(o, len) * U;
         m.n_buckets = m.max_units + max_cost + 1;
     }
+    m.inv_c_min = (65536 + m.c_min - 1) / m.c_min;
+    for (int s = 0; s < 5; ++s) {
+        m.u_mm_pk[s] = m.s_mm_pk[s] = 0;
+        for (int c = 0; c < 4; ++c) { m.u_mm_pk[s] |= (uint32_t)m.u_mm[s][c] << (8 * c); m.s_mm_pk[s] |= (uint32_t)m.s_mm[s][c] << (8 * c); }
+    }
     if (m.n_buckets > PS_MAX_BUCKETS) { err = "score range exceeds PS_MAX_BUCKETS; lower -n/-X"; return false; }
     if (len > PS_MAX_LEN) { err = "read longer than PS_MAX_LEN"; return false; }
     if (m.max_gapo > 7 || m.max_gape > 7) { err = "gap limits above 7 are not supported by the packed stack entry"; return false; }

@@ -205,6 +205,7 @@ static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases
     DevBuf<uint32_t> queue; queue.alloc(1); queue.zero(s);
     a.pool = pool.p; a.pool_cap = pool_cap; a.heads = heads.p; a.wide = wide ? 1 : 0; a.stats = b.d_stats.p + 1;
     a.queue = queue.p; a.fetch_min = ctx->fetch_min;
+    DevBuf<uint32_t> riters; if (ctx->want_read_iters) { riters.alloc(n); riters.zero(s); a.read_iters = riters.p; }
     { EvTimer t(s); launch_backtrack(a, blocks, lm, s); PS_HIP(hipGetLastError()); b.tm.ms_backtrack += t.stop(); ++b.tm.n_backtrack_launches; }
     // compact the hit lists on the device, then one download
     EvTimer tc(s);
@@ -214,6 +215,7 @@ static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases
     PS_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, cnt.p, off.p, n, s));
     DevBuf<uint8_t> tmp; tmp.alloc(tb ? tb : 1);
     PS_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, cnt.p, off.p, n, s));
+    if (ctx->want_read_iters) { ctx->read_iters.resize(n); riters.download(ctx->read_iters.data(), n, s); }
     out.n_aln.resize(n); out.status.resize(n); out.off.resize((size_t)n + 1);
     n_aln.download(out.n_aln.data(), n, s); status.download(out.status.data(), n, s); off.download(out.off.data(), n, s);
     PS_HIP(hipStreamSynchronize(s));

@@ -23,9 +23,10 @@ typedef uint32_t bwtint;
 static const bwtint PS_NIL_ROW = 0xFFFFFFFFu;
 
 // ---- FM index: one 64-byte block per 192 BWT symbols --------------------
-// cnt[c] = occurrences of c in all earlier blocks; sym = 12 words x 16
-// symbols, symbol j of a word at bits [2j,2j+1].  64 B = one HBM burst pair /
-// half an L2 line; 5.33 bits per base.
+// cnt[c] = occurrences of c in all earlier blocks; sym[0..5] = low bit plane,
+// sym[6..11] = high bit plane of the 192 symbols (symbol p: bit p&31 of word
+// p>>5) -- one prefix mask + three popcounts per 32 symbols give all four
+// counts.  64 B = half an L2 line; 5.33 bits per base.
 static const int PS_BLK_SYMS = 192;
 struct OccBlock { uint32_t cnt[4]; uint32_t sym[12]; };
 
@@ -46,8 +47,9 @@ struct IndexView {
 // mode: units == score == profile-derived integer cost (our model; oracle/ps_oracle.h).
 struct Model {
     uint8_t u_mm[5][4], s_mm[5][4];   // [search-orientation read code][text char]
+    uint32_t u_mm_pk[5], s_mm_pk[5];  // the same, one word per read code (byte c = text char): register selects on the device
     int32_t u_gapo_ins, s_gapo_ins, u_gapo_del, s_gapo_del, u_gape, s_gape;
-    int32_t s_stop, u_tight, c_min, max_units, n_buckets;
+    int32_t s_stop, u_tight, c_min, inv_c_min /* ceil(65536/c_min): x/c_min == x*inv>>16 for the small x used */, max_units, n_buckets;
     int32_t max_gapo, max_gape, mode_gape, indel_end_skip, max_del_occ, max_entries;
     int32_t seed_len, max_seed_diff, max_top2, use_seed, len, profile;
 };
@@ -95,6 +97,7 @@ struct BtArgs {
     uint32_t *heads;                                  // wide stack only: heads[lane*PS_MAX_BUCKETS + bucket]
     int wide;
     uint32_t *queue;                                  // next unassigned read (waves take chunks of it)
+    uint32_t *read_iters;                             // optional: iterations spent per read (profiling aid)
     int fetch_min;                                    // idle lanes a wave waits for before it loads new reads
     KStats *stats;
 };
