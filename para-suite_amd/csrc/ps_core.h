@@ -412,6 +412,7 @@ PS_HD void bt_iter(const BtArgs &a, BtLane &L, BtMem &m, int fetch_r)
 {
     const Model &md = a.md;
     const int len = a.len;
+    if (L.mode == M_EXIT) return;          // retired lane: must not reach the memory step below
     ++L.st.iters;
     if (L.mode == M_FETCH) {
         if (fetch_r < 0) return;
@@ -453,6 +454,7 @@ PS_HD void bt_iter(const BtArgs &a, BtLane &L, BtMem &m, int fetch_r)
         if (mleft == 0 && (L.state == ST_M || md.mode_gape || L.n_gape == md.max_gape)) L.mode = M_EXACT;
         else L.mode = M_EXPAND;
     }
+    if (L.mode != M_EXACT && L.mode != M_EXPAND) return;
     // ---- the memory step, shared by both search modes: Occ(k-1,.) and Occ(l,.) -> the four child intervals ----
     uint32_t ck[4], cl[4];
     occ_pair4(a.ix, L.k, L.l, ck, cl, L.st);

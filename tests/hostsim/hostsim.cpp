@@ -110,7 +110,7 @@ int hs_aln(void *p, const Model *md, int n_reads, int len, const uint8_t *codes,
         any = false;
         for (int t = 0; t < n_lanes; ++t) {
             BtLane &L = lanes[t];
-            if (L.mode == M_EXIT) continue;
+            if (L.mode == M_EXIT) { BtMem mm{}; bt_iter<false>(a, L, mm, -1); continue; }   // the kernel calls retired lanes too: must be a no-op
             BtMem m; uint8_t *mine = lm.data() + (size_t)t * lmb;
             bt_mem_bind(m, mine, len, seed_len);
             m.pool = pool.data() + (size_t)t * pool_cap * (wide ? sizeof(Entry) : sizeof(Entry16));
