@@ -191,11 +191,12 @@ void ps_batch_free(ps_batch *b) { delete b; }
 int64_t ps_batch_n(ps_batch *b) { return b->b->rs.n; }
 int ps_batch_search(ps_batch *b) { PS_TRY batch_search(*b->b); return 0; PS_CATCH_INT }
 int ps_batch_select_hard(ps_batch *b, uint64_t before, uint64_t *after) { PS_TRY batch_select_hard(*b->b, before, after); return 0; PS_CATCH_INT }
-int ps_batch_select_easy(ps_batch *b, int threads) { PS_TRY batch_select_easy(*b->b, threads); return 0; PS_CATCH_INT }
+int ps_batch_select_easy(ps_batch *b, int threads) { PS_TRY b->b->ctx->host_threads = threads > 0 ? threads : 1; batch_select_easy(*b->b, threads); return 0; PS_CATCH_INT }
 int ps_batch_locate(ps_batch *b) { PS_TRY batch_locate(*b->b); return 0; PS_CATCH_INT }
 int ps_batch_run(ps_batch *b, int threads)
 {
     PS_TRY
+        b->b->ctx->host_threads = threads > 0 ? threads : 1;
         batch_search(*b->b);
         batch_select_hard(*b->b, 0, nullptr);
         batch_select_easy(*b->b, threads);

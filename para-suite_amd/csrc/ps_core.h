@@ -306,8 +306,11 @@ PS_HD void bt_push(const BtArgs &a, BtLane &L, BtMem &m, int i, bwtint k, bwtint
         store_entry(&pool[idx], e);
         m.heads[score] = idx;
     } else {
-        if (L.bump >= a.pool_cap) { L.status = RS_OVERFLOW_POOL; return; }
-        const uint32_t idx = L.bump++;
+        // the slot of the entry popped last is reused first (no free list to maintain), then fresh slots
+        uint32_t idx = L.free_head;
+        if (idx != PS_NIL) L.free_head = PS_NIL;
+        else if (L.bump < a.pool_cap) idx = L.bump++;
+        else { L.status = RS_OVERFLOW_POOL; return; }
         const uint32_t next = bm_test(L, score) ? (uint32_t)m.heads16[score] : PS_NIL16;
         Entry16 e;
         e.k = k; e.l = l;
@@ -338,7 +341,9 @@ PS_HD void bt_pop(const BtArgs &a, BtLane &L, BtMem &m)
         L.state = e.state; L.ldp = e.last_diff_pos;
     } else {
         Entry16 e;
-        load16(reinterpret_cast<const Entry16 *>(m.pool) + m.heads16[b], e);
+        const uint32_t h = m.heads16[b];
+        load16(reinterpret_cast<const Entry16 *>(m.pool) + h, e);
+        L.free_head = h;
         const uint32_t next = e.b >> 16;
         if (next == PS_NIL16) bm_clr(L, b); else m.heads16[b] = (uint16_t)next;
         L.k = e.k; L.l = e.l;

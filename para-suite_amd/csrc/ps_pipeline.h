@@ -31,6 +31,15 @@ struct Timing {
     int n_width_launches = 0, n_backtrack_launches = 0;
 };
 
+struct PinBuf {                     // page-locked host staging (D2H at PCIe rate instead of pageable copies)
+    void *p = nullptr; size_t bytes = 0;
+    PinBuf() {}
+    PinBuf(const PinBuf &) = delete;
+    PinBuf &operator=(const PinBuf &) = delete;
+    ~PinBuf() { if (p) (void)hipHostFree(p); }
+    void *get(size_t need) { if (need > bytes) { if (p) (void)hipHostFree(p); p = nullptr; bytes = 0; PS_HIP(hipHostMalloc(&p, need, hipHostMallocDefault)); bytes = need; } return p; }
+};
+
 struct Ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -40,7 +49,17 @@ struct Ctx {
     uint32_t pool_cap[3] = {4096, 65535, 2000064};   // stack entries per lane: 16-byte narrow tiers, then the wide tier
     int aln_cap[3] = {8, 256, 65536};
     bool want_read_iters = false; std::vector<uint32_t> read_iters;   // profiling aid: last launch's per-read iterations
-    int fetch_min = 8;             // idle lanes a wave collects before it loads new reads
+    int fetch_min = 8;
+    int host_threads = 8;
+    // grow-only device workspace and pinned staging, reused by every search (hipMalloc/hipFree of GBs per call is slow)
+    std::map<std::string, DevBuf<uint8_t>> ws; std::map<std::string, PinBuf> pin;
+    template <class T> T *ws_get(const std::string &name, size_t count) {
+        DevBuf<uint8_t> &b = ws[name];
+        const size_t need = count * sizeof(T);
+        if (b.n < need) b.alloc(need + need / 8);
+        return reinterpret_cast<T *>(b.p);
+    }
+    template <class T> T *pin_get(const std::string &name, size_t count) { return reinterpret_cast<T *>(pin[name].get(count * sizeof(T) + 64)); }             // idle lanes a wave collects before it loads new reads
     ~Ctx();
 };
 

@@ -172,12 +172,15 @@ static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases
 {
     Ctx *ctx = b.ctx; hipStream_t s = ctx->stream;
     const int len = md.len, seed_len = md.seed_len;
-    DevBuf<uint32_t> w, cwb, cswb; DevBuf<uint8_t> status; DevBuf<AlnRec> alns; DevBuf<int32_t> n_aln;
-    w.alloc((size_t)(len + 1) * n); cwb.alloc((size_t)lm_ncw(len) * n); cswb.alloc((size_t)(lm_ncsw(seed_len) + 1) * n);
-    status.alloc(n); alns.alloc((size_t)n * aln_cap); n_aln.alloc(n);
+    uint32_t *w = ctx->ws_get<uint32_t>("w", (size_t)(len + 1) * n);
+    uint32_t *cwb = ctx->ws_get<uint32_t>("cwb", (size_t)lm_ncw(len) * n);
+    uint32_t *cswb = ctx->ws_get<uint32_t>("cswb", (size_t)(lm_ncsw(seed_len) + 1) * n);
+    uint8_t *status = ctx->ws_get<uint8_t>("status", n);
+    AlnRec *alns = ctx->ws_get<AlnRec>("alns", (size_t)n * aln_cap);
+    int32_t *n_aln = ctx->ws_get<int32_t>("n_aln", n);
     WidthArgs wa;
     wa.ix = ctx->ix.view; wa.n_reads = n; wa.len = len; wa.seed_len = seed_len; wa.use_seed = md.use_seed;
-    wa.bases = d_bases; wa.nmask = d_nmask; wa.w = w.p; wa.cwb = cwb.p; wa.cswb = cswb.p; wa.stats = b.d_stats.p + 0;
+    wa.bases = d_bases; wa.nmask = d_nmask; wa.w = w; wa.cwb = cwb; wa.cswb = cswb; wa.stats = b.d_stats.p + 0;
     { EvTimer t(s); launch_width(wa, s); PS_HIP(hipGetLastError()); b.tm.ms_width += t.stop(); ++b.tm.n_width_launches; }
     int dev_cus = 256;
     { hipDeviceProp_t p; if (hipGetDeviceProperties(&p, ctx->device) == hipSuccess && p.multiProcessorCount > 0) dev_cus = p.multiProcessorCount; }
@@ -191,43 +194,49 @@ static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases
     if (blocks > need) blocks = need;
     // bound the lanes by stack memory (the widest tier keeps 64 MB per lane)
     const size_t per_lane = (size_t)pool_cap * (wide ? sizeof(Entry) : 16) + (wide ? PS_MAX_BUCKETS * 4 : 0);
-    const size_t max_lanes = ((size_t)48 << 30) / per_lane;
+    const size_t max_lanes = ((size_t)(wide ? 32 : 16) << 30) / per_lane;
     if ((size_t)blocks * 256 > max_lanes) blocks = (int)std::max<size_t>(1, max_lanes / 256);
     const int n_lanes = blocks * 256;
-    DevBuf<uint8_t> pool; DevBuf<uint32_t> heads;
-    pool.alloc((size_t)n_lanes * pool_cap * (wide ? sizeof(Entry) : 16));
-    if (wide) heads.alloc((size_t)n_lanes * PS_MAX_BUCKETS);
+    uint8_t *pool = ctx->ws_get<uint8_t>("pool", (size_t)n_lanes * pool_cap * (wide ? sizeof(Entry) : 16));
+    uint32_t *heads = wide ? ctx->ws_get<uint32_t>("heads", (size_t)n_lanes * PS_MAX_BUCKETS) : nullptr;
+    uint32_t *queue = ctx->ws_get<uint32_t>("queue", 16);
+    PS_HIP(hipMemsetAsync(queue, 0, 64, s));
     BtArgs a; std::memset(&a, 0, sizeof a);
     a.ix = ctx->ix.view; a.md = md; a.n_reads = n; a.len = len; a.n_lanes = n_lanes;
     a.bases = d_bases; a.nmask = d_nmask; a.n_bw = (len + 15) / 16; a.n_mw = (len + 31) / 32;
-    a.w = w.p; a.cwb = cwb.p; a.cswb = cswb.p;
-    a.alns = alns.p; a.aln_cap = aln_cap; a.n_aln = n_aln.p; a.status = status.p;
-    DevBuf<uint32_t> queue; queue.alloc(1); queue.zero(s);
-    a.pool = pool.p; a.pool_cap = pool_cap; a.heads = heads.p; a.wide = wide ? 1 : 0; a.stats = b.d_stats.p + 1;
-    a.queue = queue.p; a.fetch_min = ctx->fetch_min;
-    DevBuf<uint32_t> riters; if (ctx->want_read_iters) { riters.alloc(n); riters.zero(s); a.read_iters = riters.p; }
+    a.w = w; a.cwb = cwb; a.cswb = cswb;
+    a.alns = alns; a.aln_cap = aln_cap; a.n_aln = n_aln; a.status = status;
+    a.pool = pool; a.pool_cap = pool_cap; a.heads = heads; a.wide = wide ? 1 : 0; a.stats = b.d_stats.p + 1;
+    a.queue = queue; a.fetch_min = ctx->fetch_min;
+    uint32_t *riters = nullptr;
+    if (ctx->want_read_iters) { riters = ctx->ws_get<uint32_t>("riters", n); PS_HIP(hipMemsetAsync(riters, 0, (size_t)n * 4, s)); a.read_iters = riters; }
     { EvTimer t(s); launch_backtrack(a, blocks, lm, s); PS_HIP(hipGetLastError()); b.tm.ms_backtrack += t.stop(); ++b.tm.n_backtrack_launches; }
-    // compact the hit lists on the device, then one download
+    // compact the hit lists on the device, then one download through pinned staging
     EvTimer tc(s);
-    DevBuf<uint32_t> cnt, off; cnt.alloc(n); off.alloc(n);
-    hipLaunchKernelGGL(k_clip_counts, dim3((n + 255) / 256), dim3(256), 0, s, n_aln.p, aln_cap, n, cnt.p);
+    uint32_t *cnt = ctx->ws_get<uint32_t>("cnt", n), *off = ctx->ws_get<uint32_t>("off", (size_t)n + 1);
+    hipLaunchKernelGGL(k_clip_counts, dim3((n + 255) / 256), dim3(256), 0, s, n_aln, aln_cap, n, cnt);
     size_t tb = 0;
-    PS_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, cnt.p, off.p, n, s));
-    DevBuf<uint8_t> tmp; tmp.alloc(tb ? tb : 1);
-    PS_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, cnt.p, off.p, n, s));
-    if (ctx->want_read_iters) { ctx->read_iters.resize(n); riters.download(ctx->read_iters.data(), n, s); }
-    out.n_aln.resize(n); out.status.resize(n); out.off.resize((size_t)n + 1);
-    n_aln.download(out.n_aln.data(), n, s); status.download(out.status.data(), n, s); off.download(out.off.data(), n, s);
+    PS_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, cnt, off, n, s));
+    uint8_t *tmp = ctx->ws_get<uint8_t>("scan_tmp", tb ? tb : 1);
+    PS_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tb, cnt, off, n, s));
+    if (ctx->want_read_iters) { ctx->read_iters.resize(n); PS_HIP(hipMemcpyAsync(ctx->read_iters.data(), riters, (size_t)n * 4, hipMemcpyDeviceToHost, s)); }
+    int32_t *p_na = ctx->pin_get<int32_t>("n_aln", n); uint8_t *p_st = ctx->pin_get<uint8_t>("status", n); uint32_t *p_off = ctx->pin_get<uint32_t>("off", (size_t)n + 1);
+    PS_HIP(hipMemcpyAsync(p_na, n_aln, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    PS_HIP(hipMemcpyAsync(p_st, status, (size_t)n, hipMemcpyDeviceToHost, s));
+    PS_HIP(hipMemcpyAsync(p_off, off, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     PS_HIP(hipStreamSynchronize(s));
     uint32_t last = 0;
-    if (n) { int m = out.n_aln[n - 1]; last = out.off[n - 1] + (uint32_t)(m > aln_cap ? aln_cap : (m < 0 ? 0 : m)); }
-    out.off[n] = last;
+    if (n) { int m = p_na[n - 1]; last = p_off[n - 1] + (uint32_t)(m > aln_cap ? aln_cap : (m < 0 ? 0 : m)); }
+    p_off[n] = last;
+    out.n_aln.assign(p_na, p_na + n); out.status.assign(p_st, p_st + n); out.off.assign(p_off, p_off + n + 1);
     out.alns.resize(last);
     if (last) {
-        DevBuf<AlnRec> comp; comp.alloc(last);
-        hipLaunchKernelGGL(k_gather_alns, dim3((n + 255) / 256), dim3(256), 0, s, alns.p, aln_cap, n_aln.p, off.p, n, comp.p);
-        comp.download(out.alns.data(), last, s);
+        AlnRec *comp = ctx->ws_get<AlnRec>("comp", last);
+        hipLaunchKernelGGL(k_gather_alns, dim3((n + 255) / 256), dim3(256), 0, s, alns, aln_cap, n_aln, off, n, comp);
+        AlnRec *p_al = ctx->pin_get<AlnRec>("alns", last);
+        PS_HIP(hipMemcpyAsync(p_al, comp, (size_t)last * sizeof(AlnRec), hipMemcpyDeviceToHost, s));
         PS_HIP(hipStreamSynchronize(s));
+        std::memcpy(out.alns.data(), p_al, (size_t)last * sizeof(AlnRec));
     }
     b.tm.ms_compact += tc.stop();
 }
@@ -474,12 +483,14 @@ void batch_locate(Batch &b)
     for (int64_t g = 0; g < N; ++g) if (b.hits[g].type != 0) { row_of[g] = (int64_t)rows.size(); rows.push_back(b.hits[g].sa); }
     const size_t multi_base = rows.size();
     for (const Multi &m : b.multis) rows.push_back(m.row);
-    std::vector<bwtint> pos(rows.size());
+    bwtint *pos = ctx->pin_get<bwtint>("pos", rows.size() + 1);
     if (!rows.empty()) {
-        DevBuf<bwtint> d_rows, d_pos; d_rows.alloc(rows.size()); d_pos.alloc(rows.size());
-        d_rows.upload(rows.data(), rows.size(), s);
-        { EvTimer t(s); launch_sa2pos(ctx->ix.view, d_rows.p, d_pos.p, (int)rows.size(), b.d_stats.p + 2, s); PS_HIP(hipGetLastError()); b.tm.ms_sa2pos += t.stop(); }
-        d_pos.download(pos.data(), rows.size(), s);
+        bwtint *d_rows = ctx->ws_get<bwtint>("rows", rows.size()), *d_pos = ctx->ws_get<bwtint>("pos", rows.size());
+        bwtint *p_rows = ctx->pin_get<bwtint>("rows", rows.size());
+        std::memcpy(p_rows, rows.data(), rows.size() * sizeof(bwtint));
+        PS_HIP(hipMemcpyAsync(d_rows, p_rows, rows.size() * sizeof(bwtint), hipMemcpyHostToDevice, s));
+        { EvTimer t(s); launch_sa2pos(ctx->ix.view, d_rows, d_pos, (int)rows.size(), b.d_stats.p + 2, s); PS_HIP(hipGetLastError()); b.tm.ms_sa2pos += t.stop(); }
+        PS_HIP(hipMemcpyAsync(pos, d_pos, rows.size() * sizeof(bwtint), hipMemcpyDeviceToHost, s));
         PS_HIP(hipStreamSynchronize(s));
         PS_HIP(hipMemcpy(&b.st_sa2pos, b.d_stats.p + 2, sizeof(KStats), hipMemcpyDeviceToHost));
     }
@@ -487,25 +498,39 @@ void batch_locate(Batch &b)
     std::vector<std::vector<RefineItem>> items(b.bins.size());
     struct Back { int64_t g; int32_t multi; };             // multi < 0: main hit
     std::vector<std::vector<Back>> back(b.bins.size());
-    for (int64_t g = 0; g < N; ++g) {
+    {   // strand / MAPQ / alternative-hit filter: independent per read
+        int nt = std::max(1, std::min(ctx->host_threads, 64));
+        auto work = [&](int t) {
+            for (int64_t g = N * t / nt; g < N * (t + 1) / nt; ++g) {
+                Hit &h = b.hits[g];
+                const int len = b.rs.len[g];
+                if (h.type != 0) {
+                    int strand = 0;
+                    h.pos = to_forward(pos[row_of[g]], l_pac, len + h.ref_shift, strand);
+                    h.strand = strand;
+                    h.mapq = approx_mapq(h, ctx->opt, len);
+                    if (h.pos < 0) h.type = 0;
+                }
+                int kept = 0;
+                for (int j = 0; j < h.n_multi; ++j) {
+                    Multi &m = b.multis[h.multi_begin + j];
+                    int strand = 0;
+                    m.pos = to_forward(pos[multi_base + h.multi_begin + j], l_pac, len + m.ref_shift, strand);
+                    m.strand = strand;
+                    if (m.pos != h.pos && m.pos >= 0) b.multis[h.multi_begin + kept++] = m;
+                }
+                h.n_multi = kept;
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+        work(0);
+        for (auto &x : th) x.join();
+    }
+    for (int64_t g = 0; g < N; ++g) {                       // gapped hits go to the banded-DP kernel
         Hit &h = b.hits[g];
-        const int len = b.rs.len[g], bi = b.read_bin[g];
-        if (h.type != 0) {
-            int strand = 0;
-            h.pos = to_forward(pos[row_of[g]], l_pac, len + h.ref_shift, strand);
-            h.strand = strand;
-            h.mapq = approx_mapq(h, ctx->opt, len);
-            if (h.pos < 0) h.type = 0;
-        }
-        int kept = 0;
-        for (int j = 0; j < h.n_multi; ++j) {
-            Multi &m = b.multis[h.multi_begin + j];
-            int strand = 0;
-            m.pos = to_forward(pos[multi_base + h.multi_begin + j], l_pac, len + m.ref_shift, strand);
-            m.strand = strand;
-            if (m.pos != h.pos && m.pos >= 0) b.multis[h.multi_begin + kept++] = m;
-        }
-        h.n_multi = kept;
+        if (h.n_multi == 0 && !(h.type != 0 && h.n_gapo)) continue;
+        const int bi = b.read_bin[g];
         for (int j = 0; j < h.n_multi; ++j) {
             Multi &m = b.multis[h.multi_begin + j];
             if (m.gap) { items[bi].push_back(RefineItem{b.read_local[g], (bwtint)m.pos, m.ref_shift, m.strand}); back[bi].push_back(Back{g, j}); }
