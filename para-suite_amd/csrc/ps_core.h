@@ -290,6 +290,7 @@ PS_HD void bt_push(const BtArgs &a, BtLane &L, BtMem &m, int i, bwtint k, bwtint
                    int n_ins, int n_del, int state, bool is_diff, int score, int units)
 {
     if (units > L.max_units) return;        // cannot be afforded (no-op with stock costs)
+    if (score >= a.md.n_buckets) { L.status = RS_BAD_SCORE; return; }   // cannot happen (make_model sizes the buckets); never write past the heads
     if (WIDE) {
         Entry *pool = reinterpret_cast<Entry *>(m.pool);
         uint32_t idx;

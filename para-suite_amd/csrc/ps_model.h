@@ -140,8 +140,17 @@ inline bool make_model(const Options &o, int len, Model &m, std::string &err)
         m.u_gapo_ins = m.u_gapo_del = 1; m.s_gapo_ins = m.s_gapo_del = o.s_gapo;
         m.u_gape = o.mode_gape ? 1 : 0; m.s_gape = o.s_gape;
         m.s_stop = o.s_mm; m.u_tight = 1; m.c_min = 1; m.max_units = md;
-        m.n_buckets = (md + 1) * o.s_mm + (m.max_gapo + 1) * o.s_gapo + (o.max_gape + 1) * o.s_gape;
-        if (m.n_buckets < 1) m.n_buckets = 1;
+        // score buckets: only entries whose units fit the budget are ever pushed, so the largest score on a
+        // stack is max{a*s_mm + b*s_gapo + c*s_gape : a+b+c(u_gape) <= md, b <= max_gapo, c <= max_gape, c only with b}
+        int top = 0;
+        for (int bb = 0; bb <= m.max_gapo; ++bb)
+            for (int cc = 0; cc <= (bb ? o.max_gape : 0); ++cc) {
+                const int used = bb + (o.mode_gape ? cc : 0);
+                if (used > md) continue;
+                const int sc = (md - used) * o.s_mm + bb * o.s_gapo + cc * o.s_gape;
+                if (sc > top) top = sc;
+            }
+        m.n_buckets = top + 1;
     } else {
         const int U = o.unit;
         m.max_gapo = o.max_gapo;
@@ -161,7 +170,8 @@ inline bool make_model(const Options &o, int len, Model &m, std::string &err)
         if (m.c_min < 1) m.c_min = 1;
         m.s_stop = U; m.u_tight = U;
         m.max_units = budget_diffs(o, len) * U;
-        m.n_buckets = m.max_units + max_cost + 1;
+        m.n_buckets = m.max_units + 1;      // profile mode: score == units, and unaffordable children are not pushed
+        (void)max_cost;
     }
     m.inv_c_min = (65536 + m.c_min - 1) / m.c_min;
     for (int s = 0; s < 5; ++s) {

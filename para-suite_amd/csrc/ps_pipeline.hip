@@ -256,7 +256,10 @@ void batch_search(Batch &b)
         bin.h_n_aln.swap(so.n_aln); bin.h_off.swap(so.off); bin.h_alns.swap(so.alns);
         bin.overflow.clear();
         std::vector<int32_t> todo;
-        for (int r = 0; r < n; ++r) if (so.status[r] != RS_OK) todo.push_back(r);
+        for (int r = 0; r < n; ++r) {
+            if (so.status[r] == RS_BAD_SCORE) throw Error("internal: score outside the bucket range");
+            if (so.status[r] != RS_OK) todo.push_back(r);
+        }
         for (int tier = 1; tier < 3 && !todo.empty(); ++tier) {
             b.n_overflow[tier] += (int64_t)todo.size();
             const int m = (int)todo.size();

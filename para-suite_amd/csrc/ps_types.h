@@ -74,7 +74,7 @@ struct AlnRec {
     uint8_t n_mm, n_gapo, n_gape, n_ins, n_del, pad[3];
 };  // 20 B
 
-enum { RS_OK = 0, RS_OVERFLOW_POOL = 1, RS_OVERFLOW_ALN = 2 };
+enum { RS_OK = 0, RS_OVERFLOW_POOL = 1, RS_OVERFLOW_ALN = 2, RS_BAD_SCORE = 3 };
 
 struct KStats {            // per-launch counters (roofline accounting)
     unsigned long long occ_pairs, occ_same_blk, nodes, pushes, pops, lf_steps, iters, exact_steps;
