@@ -176,7 +176,7 @@ PS_HD void wchain_step(const IndexView &ix, WChain &c, int base, uint32_t &w_out
 }
 
 // ----------------------------------------------------- backtracking lane ---
-enum { M_FETCH = 0, M_POP = 1, M_EXACT = 2, M_EXPAND = 3, M_EXIT = 4 };
+enum { M_FETCH = 0, M_POP = 1, M_EXACT = 2, M_EXPAND = 3, M_EXIT = 4, M_HIT = 5 };
 
 struct BtLane {
     int r, mode;
@@ -413,13 +413,21 @@ PS_HD void bt_hit(const BtArgs &a, BtLane &L, BtMem &m)
 
 // One iteration of a lane.  fetch_r: the read this lane may take if it is idle (M_FETCH): < 0 = none offered
 // now (stay idle), >= n_reads = the input is exhausted (retire), else the read index.
+// serve_hit: lanes that reached a hit (M_HIT) record it now; the kernel batches this rare, long path over
+// several lanes of a wave instead of running it for one lane at a time.
 template <bool WIDE>
-PS_HD void bt_iter(const BtArgs &a, BtLane &L, BtMem &m, int fetch_r)
+PS_HD void bt_iter(const BtArgs &a, BtLane &L, BtMem &m, int fetch_r, bool serve_hit)
 {
     const Model &md = a.md;
     const int len = a.len;
     if (L.mode == M_EXIT) return;          // retired lane: must not reach the memory step below
     ++L.st.iters;
+    if (L.mode == M_HIT) {
+        if (!serve_hit) return;
+        L.mode = M_POP;
+        bt_hit(a, L, m);                   // may finish the read (mode becomes M_FETCH)
+        return;
+    }
     if (L.mode == M_FETCH) {
         if (fetch_r < 0) return;
         if (fetch_r >= a.n_reads) { L.mode = M_EXIT; return; }
@@ -456,7 +464,7 @@ PS_HD void bt_iter(const BtArgs &a, BtLane &L, BtMem &m, int fetch_r)
         if (rem < 0) return;
         const int mleft = (int)(((uint32_t)rem * (uint32_t)md.inv_c_min) >> 16);     // rem / c_min
         if (L.i > 0 && mleft < (int)(m.cw[L.i - 1] & 0x7f)) return;
-        if (L.i == 0) { bt_hit(a, L, m); return; }
+        if (L.i == 0) { L.mode = M_HIT; return; }
         if (mleft == 0 && (L.state == ST_M || md.mode_gape || L.n_gape == md.max_gape)) L.mode = M_EXACT;
         else L.mode = M_EXPAND;
     }
@@ -474,7 +482,7 @@ PS_HD void bt_iter(const BtArgs &a, BtLane &L, BtMem &m, int fetch_r)
         const bwtint k2 = sel4(nk, c), l2 = sel4(nl, c);
         if (k2 > l2) { L.mode = M_POP; return; }
         L.k = k2; L.l = l2; --L.i;
-        if (L.i == 0) { L.mode = M_POP; bt_hit(a, L, m); }
+        if (L.i == 0) L.mode = M_HIT;
         return;
     }
     {

@@ -99,12 +99,14 @@ __global__ void __launch_bounds__(256) k_backtrack(BtArgs a, int lm_stride)
     bool exhausted = false;
     for (;;) {
         const bool want = L.mode == M_FETCH;
-        const unsigned long long wmask = __ballot(want), lmask = __ballot(L.mode != M_EXIT);
+        const unsigned long long wmask = __ballot(want), lmask = __ballot(L.mode != M_EXIT), hmask = __ballot(L.mode == M_HIT);
         if (lmask == 0) break;
+        const bool stalled = (wmask | hmask) == lmask;          // nobody can advance without being served
+        const bool serve_hit = hmask != 0 && (__popcll(hmask) >= a.hit_min || stalled);
         int fetch_r = -1;
         if (wmask) {
             const int cnt = __popcll(wmask);
-            if (cnt >= a.fetch_min || wmask == lmask) {
+            if (cnt >= a.fetch_min || stalled) {
                 const int rank = __popcll(wmask & lane_lt);
                 int served = 0;
                 while (served < cnt) {
@@ -124,7 +126,7 @@ __global__ void __launch_bounds__(256) k_backtrack(BtArgs a, int lm_stride)
                 if (want && fetch_r < 0 && exhausted) fetch_r = a.n_reads;   // nothing left: this lane retires
             }
         }
-        bt_iter<WIDE>(a, L, m, fetch_r);
+        bt_iter<WIDE>(a, L, m, fetch_r, serve_hit);
     }
     flush_stats(a.stats, L.st);
 }

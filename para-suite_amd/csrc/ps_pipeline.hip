@@ -207,7 +207,7 @@ static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases
     a.w = w; a.cwb = cwb; a.cswb = cswb;
     a.alns = alns; a.aln_cap = aln_cap; a.n_aln = n_aln; a.status = status;
     a.pool = pool; a.pool_cap = pool_cap; a.heads = heads; a.wide = wide ? 1 : 0; a.stats = b.d_stats.p + 1;
-    a.queue = queue; a.fetch_min = ctx->fetch_min;
+    a.queue = queue; a.fetch_min = ctx->fetch_min; a.hit_min = ctx->hit_min;
     uint32_t *riters = nullptr;
     if (ctx->want_read_iters) { riters = ctx->ws_get<uint32_t>("riters", n); PS_HIP(hipMemsetAsync(riters, 0, (size_t)n * 4, s)); a.read_iters = riters; }
     { EvTimer t(s); launch_backtrack(a, blocks, lm, s); PS_HIP(hipGetLastError()); b.tm.ms_backtrack += t.stop(); ++b.tm.n_backtrack_launches; }

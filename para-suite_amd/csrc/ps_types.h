@@ -98,6 +98,7 @@ struct BtArgs {
     int wide;
     uint32_t *queue;                                  // next unassigned read (waves take chunks of it)
     uint32_t *read_iters;                             // optional: iterations spent per read (profiling aid)
+    int hit_min;                                      // lanes with a pending hit a wave collects before it records them
     int fetch_min;                                    // idle lanes a wave waits for before it loads new reads
     KStats *stats;
 };

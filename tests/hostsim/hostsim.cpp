@@ -110,14 +110,14 @@ int hs_aln(void *p, const Model *md, int n_reads, int len, const uint8_t *codes,
         any = false;
         for (int t = 0; t < n_lanes; ++t) {
             BtLane &L = lanes[t];
-            if (L.mode == M_EXIT) { BtMem mm{}; bt_iter<false>(a, L, mm, -1); continue; }   // the kernel calls retired lanes too: must be a no-op
+            if (L.mode == M_EXIT) { BtMem mm{}; bt_iter<false>(a, L, mm, -1, true); continue; }   // the kernel calls retired lanes too: must be a no-op
             BtMem m; uint8_t *mine = lm.data() + (size_t)t * lmb;
             bt_mem_bind(m, mine, len, seed_len);
             m.pool = pool.data() + (size_t)t * pool_cap * (wide ? sizeof(Entry) : sizeof(Entry16));
             m.heads = a.heads + (size_t)t * PS_MAX_BUCKETS;
             int fr = -1;                                   // static hand-out here; the kernel deals reads from a queue
             if (L.mode == M_FETCH) { fr = next[t] < n_reads ? next[t] : n_reads; next[t] += n_lanes; }
-            if (wide) bt_iter<true>(a, L, m, fr); else bt_iter<false>(a, L, m, fr);
+            if (wide) bt_iter<true>(a, L, m, fr, (t & 1) != 0 || L.mode != M_HIT || (L.st.iters & 3) == 0); else bt_iter<false>(a, L, m, fr, (t & 1) != 0 || (L.st.iters & 3) == 0);
             any = true;
         }
     }
