@@ -292,7 +292,7 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bt if dominant_bt else alg_w,
                          "avg_launch_ms": ms_bt if dominant_bt else ms_w},
             "kernels_ms_per_step": {k: acc[k] / K for k in ("ms_width", "ms_backtrack", "ms_compact", "ms_select", "ms_sa2pos",
-                                                            "ms_refine", "ms_host_post")},
+                                                            "ms_refine", "ms_host_post", "ms_classify", "ms_rows", "ms_sel_hard", "ms_sel_easy")},
             "kstats": {"backtrack": ks_bt, "width": ks_w, "sa2pos": ks_sa},
             "mapped_frac": float((hits["type"] != 0).mean()),
             "overflow_reads": [int(acc["n_overflow_tier1"] / K), int(acc["n_overflow_tier2"] / K)],

@@ -83,6 +83,7 @@ typedef struct {
     double ms_width, ms_backtrack, ms_compact, ms_select, ms_sa2pos, ms_refine, ms_host_post, ms_total;
     int32_t n_width_launches, n_backtrack_launches;
     int64_t n_overflow_tier1, n_overflow_tier2;
+    double ms_classify, ms_rows, ms_sel_hard, ms_sel_easy;   /* host sub-stages */
 } ps_timing;
 typedef struct { uint64_t occ_pairs, occ_same_blk, nodes, pushes, pops, lf_steps, iters, exact_steps; } ps_kstats;
 

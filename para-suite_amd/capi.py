@@ -23,7 +23,8 @@ class Timing(C.Structure):
     _fields_ = [("ms_width", C.c_double), ("ms_backtrack", C.c_double), ("ms_compact", C.c_double),
                 ("ms_select", C.c_double), ("ms_sa2pos", C.c_double), ("ms_refine", C.c_double),
                 ("ms_host_post", C.c_double), ("ms_total", C.c_double), ("n_width_launches", C.c_int32),
-                ("n_backtrack_launches", C.c_int32), ("n_overflow_tier1", C.c_int64), ("n_overflow_tier2", C.c_int64)]
+                ("n_backtrack_launches", C.c_int32), ("n_overflow_tier1", C.c_int64), ("n_overflow_tier2", C.c_int64),
+                ("ms_classify", C.c_double), ("ms_rows", C.c_double), ("ms_sel_hard", C.c_double), ("ms_sel_easy", C.c_double)]
 
 
 class KStats(C.Structure):

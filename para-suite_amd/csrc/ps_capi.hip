@@ -252,6 +252,7 @@ int ps_batch_timing(ps_batch *b, ps_timing *o)
         const Timing &t = b->b->tm;
         o->ms_width = t.ms_width; o->ms_backtrack = t.ms_backtrack; o->ms_compact = t.ms_compact; o->ms_select = t.ms_select;
         o->ms_sa2pos = t.ms_sa2pos; o->ms_refine = t.ms_refine; o->ms_host_post = t.ms_host_post; o->ms_total = t.ms_total;
+        o->ms_classify = t.ms_classify; o->ms_rows = t.ms_rows; o->ms_sel_hard = t.ms_sel_hard; o->ms_sel_easy = t.ms_sel_easy;
         o->n_width_launches = t.n_width_launches; o->n_backtrack_launches = t.n_backtrack_launches;
         o->n_overflow_tier1 = b->b->n_overflow[1]; o->n_overflow_tier2 = b->b->n_overflow[2];
         return 0;

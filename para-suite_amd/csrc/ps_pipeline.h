@@ -27,7 +27,7 @@ struct Hit {
 };
 
 struct Timing {
-    double ms_width = 0, ms_backtrack = 0, ms_compact = 0, ms_select = 0, ms_sa2pos = 0, ms_refine = 0, ms_host_post = 0, ms_total = 0;
+    double ms_width = 0, ms_backtrack = 0, ms_compact = 0, ms_select = 0, ms_sa2pos = 0, ms_refine = 0, ms_host_post = 0, ms_total = 0, ms_classify = 0, ms_rows = 0, ms_sel_hard = 0, ms_sel_easy = 0;
     int n_width_launches = 0, n_backtrack_launches = 0;
 };
 
@@ -49,7 +49,7 @@ struct Ctx {
     uint32_t pool_cap[3] = {8192, 65535, 2000064};   // stack entries per lane: 16-byte narrow tiers, then the wide tier
     int aln_cap[3] = {8, 256, 65536};
     bool want_read_iters = false; std::vector<uint32_t> read_iters;   // profiling aid: last launch's per-read iterations
-    int fetch_min = 8, hit_min = 8;
+    int fetch_min = 8, hit_min = 1;    // batching hits costs more in idle lanes than it saves (measured)
     int host_threads = 8;
     // grow-only device workspace and pinned staging, reused by every search (hipMalloc/hipFree of GBs per call is slow)
     std::map<std::string, DevBuf<uint8_t>> ws; std::map<std::string, PinBuf> pin;
@@ -68,7 +68,9 @@ struct Bin {
     std::vector<int32_t> ids;                 // global read index of every local read
     DevBuf<uint32_t> bases, nmask, w; DevBuf<uint8_t> cwb, cswb, status; DevBuf<AlnRec> alns; DevBuf<int32_t> n_aln;
     std::vector<uint32_t> h_bases, h_nmask;   // host copy (tier re-runs gather from it)
-    std::vector<int32_t> h_n_aln; std::vector<uint32_t> h_off; std::vector<AlnRec> h_alns;   // compact hit lists
+    // compact hit lists of the first search tier, downloaded straight into page-locked memory owned by the bin
+    std::shared_ptr<PinBuf> pin_n_aln, pin_status, pin_off, pin_alns;
+    int32_t *h_n_aln = nullptr; uint32_t *h_off = nullptr; AlnRec *h_alns = nullptr;
     std::map<int32_t, std::vector<AlnRec>> overflow;                                          // reads that needed a larger tier
     int n_bw = 0, n_mw = 0;
 };

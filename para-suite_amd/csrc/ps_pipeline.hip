@@ -164,7 +164,8 @@ struct EvTimer {
     ~EvTimer() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
 };
 
-struct SearchOut { std::vector<int32_t> n_aln; std::vector<uint8_t> status; std::vector<uint32_t> off; std::vector<AlnRec> alns; };
+// results of one search launch; the buffers are page-locked and owned by the caller
+struct SearchOut { PinBuf *pn, *ps, *po, *pa; int32_t *n_aln; uint8_t *status; uint32_t *off; AlnRec *alns; };
 
 // width + backtracking kernels over n reads of one length that are already packed on the device
 static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases, const uint32_t *d_nmask,
@@ -220,7 +221,8 @@ static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases
     uint8_t *tmp = ctx->ws_get<uint8_t>("scan_tmp", tb ? tb : 1);
     PS_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tb, cnt, off, n, s));
     if (ctx->want_read_iters) { ctx->read_iters.resize(n); PS_HIP(hipMemcpyAsync(ctx->read_iters.data(), riters, (size_t)n * 4, hipMemcpyDeviceToHost, s)); }
-    int32_t *p_na = ctx->pin_get<int32_t>("n_aln", n); uint8_t *p_st = ctx->pin_get<uint8_t>("status", n); uint32_t *p_off = ctx->pin_get<uint32_t>("off", (size_t)n + 1);
+    int32_t *p_na = (int32_t *)out.pn->get((size_t)n * 4 + 64); uint8_t *p_st = (uint8_t *)out.ps->get((size_t)n + 64);
+    uint32_t *p_off = (uint32_t *)out.po->get(((size_t)n + 1) * 4 + 64);
     PS_HIP(hipMemcpyAsync(p_na, n_aln, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     PS_HIP(hipMemcpyAsync(p_st, status, (size_t)n, hipMemcpyDeviceToHost, s));
     PS_HIP(hipMemcpyAsync(p_off, off, (size_t)n * 4, hipMemcpyDeviceToHost, s));
@@ -228,16 +230,14 @@ static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases
     uint32_t last = 0;
     if (n) { int m = p_na[n - 1]; last = p_off[n - 1] + (uint32_t)(m > aln_cap ? aln_cap : (m < 0 ? 0 : m)); }
     p_off[n] = last;
-    out.n_aln.assign(p_na, p_na + n); out.status.assign(p_st, p_st + n); out.off.assign(p_off, p_off + n + 1);
-    out.alns.resize(last);
+    AlnRec *p_al = (AlnRec *)out.pa->get((size_t)last * sizeof(AlnRec) + 64);
     if (last) {
         AlnRec *comp = ctx->ws_get<AlnRec>("comp", last);
         hipLaunchKernelGGL(k_gather_alns, dim3((n + 255) / 256), dim3(256), 0, s, alns, aln_cap, n_aln, off, n, comp);
-        AlnRec *p_al = ctx->pin_get<AlnRec>("alns", last);
         PS_HIP(hipMemcpyAsync(p_al, comp, (size_t)last * sizeof(AlnRec), hipMemcpyDeviceToHost, s));
         PS_HIP(hipStreamSynchronize(s));
-        std::memcpy(out.alns.data(), p_al, (size_t)last * sizeof(AlnRec));
     }
+    out.n_aln = p_na; out.status = p_st; out.off = p_off; out.alns = p_al;
     b.tm.ms_compact += tc.stop();
 }
 
@@ -251,14 +251,16 @@ void batch_search(Batch &b)
     for (int t = 0; t < 3; ++t) b.n_overflow[t] = 0;
     for (Bin &bin : b.bins) {
         const int n = (int)bin.ids.size();
-        SearchOut so;
+        if (!bin.pin_n_aln) { bin.pin_n_aln.reset(new PinBuf()); bin.pin_status.reset(new PinBuf()); bin.pin_off.reset(new PinBuf()); bin.pin_alns.reset(new PinBuf()); }
+        SearchOut so{bin.pin_n_aln.get(), bin.pin_status.get(), bin.pin_off.get(), bin.pin_alns.get(), nullptr, nullptr, nullptr, nullptr};
         run_search(b, bin.md, n, bin.bases.p, bin.nmask.p, ctx->pool_cap[0], ctx->aln_cap[0], so);
-        bin.h_n_aln.swap(so.n_aln); bin.h_off.swap(so.off); bin.h_alns.swap(so.alns);
+        bin.h_n_aln = so.n_aln; bin.h_off = so.off; bin.h_alns = so.alns;
         bin.overflow.clear();
         std::vector<int32_t> todo;
         for (int r = 0; r < n; ++r) {
+            if (so.status[r] == RS_OK) continue;
             if (so.status[r] == RS_BAD_SCORE) throw Error("internal: score outside the bucket range");
-            if (so.status[r] != RS_OK) todo.push_back(r);
+            todo.push_back(r);
         }
         for (int tier = 1; tier < 3 && !todo.empty(); ++tier) {
             b.n_overflow[tier] += (int64_t)todo.size();
@@ -270,13 +272,15 @@ void batch_search(Batch &b)
             }
             DevBuf<uint32_t> db, dm; db.alloc(hb.size()); dm.alloc(hm.size());
             db.upload(hb.data(), hb.size(), ctx->stream); dm.upload(hm.data(), hm.size(), ctx->stream);
-            SearchOut s2;
+            PinBuf t_n, t_s, t_o, t_a;
+            SearchOut s2{&t_n, &t_s, &t_o, &t_a, nullptr, nullptr, nullptr, nullptr};
             run_search(b, bin.md, m, db.p, dm.p, ctx->pool_cap[tier], ctx->aln_cap[tier], s2);
             std::vector<int32_t> still;
             for (int q = 0; q < m; ++q) {
+                if (s2.status[q] == RS_BAD_SCORE) throw Error("internal: score outside the bucket range");
                 if (s2.status[q] != RS_OK) { still.push_back(todo[q]); continue; }
                 bin.h_n_aln[todo[q]] = s2.n_aln[q];
-                bin.overflow[todo[q]] = std::vector<AlnRec>(s2.alns.begin() + s2.off[q], s2.alns.begin() + s2.off[q + 1]);
+                bin.overflow[todo[q]] = std::vector<AlnRec>(s2.alns + s2.off[q], s2.alns + s2.off[q + 1]);
             }
             todo.swap(still);
         }
@@ -288,6 +292,7 @@ void batch_search(Batch &b)
     b.st_width = hs[0]; b.st_backtrack = hs[1];
     // classify reads for the tie-break stream: a read whose best score is reached by exactly one SA
     // interval always consumes two draws; the others ("hard") are data dependent
+    auto tcl = Clock::now();
     const int64_t N = b.rs.n;
     b.n_best.assign((size_t)N, 0); b.hard.clear(); b.easy_before.clear(); b.n_easy = 0;
     for (int64_t g = 0; g < N; ++g) {
@@ -298,7 +303,8 @@ void batch_search(Batch &b)
         if (nb == 1) ++b.n_easy;
         else if (nb >= 2) { b.hard.push_back(g); b.easy_before.push_back(b.n_easy); }
     }
-    b.hits.assign((size_t)N, Hit());
+    b.hits.resize((size_t)N);        // every record is rewritten by the selection stage
+    b.tm.ms_classify = ms_since(tcl);
     b.searched = true; b.selected_hard = b.selected = b.located = false;
     b.tm.ms_total = ms_since(t0);
 }
@@ -312,7 +318,7 @@ const AlnRec *Batch::alns_of(int64_t g, int &n) const
         auto it = bin.overflow.find(r);
         if (it != bin.overflow.end()) return it->second.data();
     }
-    return bin.h_alns.data() + bin.h_off[r];
+    return bin.h_alns + bin.h_off[r];
 }
 
 // ----------------------------------------------------- tie-break selection -----
@@ -364,7 +370,7 @@ void batch_select_hard(Batch &b, uint64_t draws_before, uint64_t *draws_after)
     b.draws_out = draws_before + 2ull * (uint64_t)b.n_easy + H;
     if (draws_after) *draws_after = b.draws_out;
     b.selected_hard = true;
-    b.tm.ms_select += ms_since(t0);
+    b.tm.ms_select += ms_since(t0); b.tm.ms_sel_hard = ms_since(t0);
 }
 
 void batch_select_easy(Batch &b, int threads)
@@ -432,7 +438,7 @@ void batch_select_easy(Batch &b, int threads)
         b.multis.insert(b.multis.end(), mul_chunks[t].begin(), mul_chunks[t].end());
     }
     b.selected = true;
-    b.tm.ms_select += ms_since(t0);
+    b.tm.ms_select += ms_since(t0); b.tm.ms_sel_easy = ms_since(t0);
 }
 
 // ------------------------------------------------- locate / MAPQ / gapped DP ----
@@ -486,6 +492,7 @@ void batch_locate(Batch &b)
     for (int64_t g = 0; g < N; ++g) if (b.hits[g].type != 0) { row_of[g] = (int64_t)rows.size(); rows.push_back(b.hits[g].sa); }
     const size_t multi_base = rows.size();
     for (const Multi &m : b.multis) rows.push_back(m.row);
+    b.tm.ms_rows = ms_since(t0);
     bwtint *pos = ctx->pin_get<bwtint>("pos", rows.size() + 1);
     if (!rows.empty()) {
         bwtint *d_rows = ctx->ws_get<bwtint>("rows", rows.size()), *d_pos = ctx->ws_get<bwtint>("pos", rows.size());
