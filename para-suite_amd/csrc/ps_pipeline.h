@@ -18,12 +18,13 @@ struct ReadSet {
 void load_reads(const char *path, ReadSet &rs);               // FASTQ or FASTA
 void reads_from_codes(int64_t n, int len, const uint8_t *codes, ReadSet &rs);
 
+static const int PS_HIT_CIGAR = 8;
 struct Multi { int64_t pos; bwtint row; int32_t gap, mm, ref_shift, strand, n_cigar; uint32_t cigar[PS_MAX_CIGAR]; };
 struct Hit {
     int64_t pos; bwtint sa;
     int32_t type, strand, mapq, n_mm, n_gapo, n_gape, ref_shift, score, c1, c2, n_cigar;
     int32_t multi_begin, n_multi;
-    uint32_t cigar[PS_MAX_CIGAR];
+    uint32_t cigar[PS_HIT_CIGAR];    // gapped main hits with more operations are rejected (needs max_gapo > 2)
 };
 
 struct Timing {

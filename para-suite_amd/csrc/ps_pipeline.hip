@@ -486,21 +486,28 @@ void batch_locate(Batch &b)
     require_device(ctx->device);
     const int64_t N = b.rs.n, l_pac = ctx->ix.ref.l_pac;
     auto t0 = Clock::now();
-    // rows to locate: main hit of every mapped read, then its alternatives
-    std::vector<bwtint> rows; rows.reserve((size_t)N + b.multis.size());
-    std::vector<int64_t> row_of((size_t)N, -1);
-    for (int64_t g = 0; g < N; ++g) if (b.hits[g].type != 0) { row_of[g] = (int64_t)rows.size(); rows.push_back(b.hits[g].sa); }
-    const size_t multi_base = rows.size();
-    for (const Multi &m : b.multis) rows.push_back(m.row);
+    // rows to locate: one slot per read (row 0 = nothing to walk for unmapped reads), then the alternatives
+    const size_t n_rows = (size_t)N + b.multis.size(), multi_base = (size_t)N;
+    bwtint *p_rows = ctx->pin_get<bwtint>("rows", n_rows + 1);
+    {
+        int nt = std::max(1, std::min(ctx->host_threads, 64));
+        auto fill = [&](int t) {
+            for (int64_t g = N * t / nt; g < N * (t + 1) / nt; ++g) p_rows[g] = b.hits[g].type != 0 ? b.hits[g].sa : 0;
+            const int64_t M = (int64_t)b.multis.size();
+            for (int64_t j = M * t / nt; j < M * (t + 1) / nt; ++j) p_rows[multi_base + j] = b.multis[j].row;
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; ++t) th.emplace_back(fill, t);
+        fill(0);
+        for (auto &x : th) x.join();
+    }
     b.tm.ms_rows = ms_since(t0);
-    bwtint *pos = ctx->pin_get<bwtint>("pos", rows.size() + 1);
-    if (!rows.empty()) {
-        bwtint *d_rows = ctx->ws_get<bwtint>("rows", rows.size()), *d_pos = ctx->ws_get<bwtint>("pos", rows.size());
-        bwtint *p_rows = ctx->pin_get<bwtint>("rows", rows.size());
-        std::memcpy(p_rows, rows.data(), rows.size() * sizeof(bwtint));
-        PS_HIP(hipMemcpyAsync(d_rows, p_rows, rows.size() * sizeof(bwtint), hipMemcpyHostToDevice, s));
-        { EvTimer t(s); launch_sa2pos(ctx->ix.view, d_rows, d_pos, (int)rows.size(), b.d_stats.p + 2, s); PS_HIP(hipGetLastError()); b.tm.ms_sa2pos += t.stop(); }
-        PS_HIP(hipMemcpyAsync(pos, d_pos, rows.size() * sizeof(bwtint), hipMemcpyDeviceToHost, s));
+    bwtint *pos = ctx->pin_get<bwtint>("pos", n_rows + 1);
+    if (n_rows) {
+        bwtint *d_rows = ctx->ws_get<bwtint>("rows", n_rows), *d_pos = ctx->ws_get<bwtint>("pos", n_rows);
+        PS_HIP(hipMemcpyAsync(d_rows, p_rows, n_rows * sizeof(bwtint), hipMemcpyHostToDevice, s));
+        { EvTimer t(s); launch_sa2pos(ctx->ix.view, d_rows, d_pos, (int)n_rows, b.d_stats.p + 2, s); PS_HIP(hipGetLastError()); b.tm.ms_sa2pos += t.stop(); }
+        PS_HIP(hipMemcpyAsync(pos, d_pos, n_rows * sizeof(bwtint), hipMemcpyDeviceToHost, s));
         PS_HIP(hipStreamSynchronize(s));
         PS_HIP(hipMemcpy(&b.st_sa2pos, b.d_stats.p + 2, sizeof(KStats), hipMemcpyDeviceToHost));
     }
@@ -516,7 +523,7 @@ void batch_locate(Batch &b)
                 const int len = b.rs.len[g];
                 if (h.type != 0) {
                     int strand = 0;
-                    h.pos = to_forward(pos[row_of[g]], l_pac, len + h.ref_shift, strand);
+                    h.pos = to_forward(pos[g], l_pac, len + h.ref_shift, strand);
                     h.strand = strand;
                     h.mapq = approx_mapq(h, ctx->opt, len);
                     if (h.pos < 0) h.type = 0;
@@ -574,6 +581,7 @@ void batch_locate(Batch &b)
             if (bk.multi < 0) {
                 int64_t rb = h.pos;
                 h.n_cigar = fix_cigar(c, nc[q], rb);
+                if (h.n_cigar > PS_HIT_CIGAR) throw Error("CIGAR with more than 8 operations (raise PS_HIT_CIGAR for max_gapo > 2)");
                 std::memcpy(h.cigar, c, sizeof h.cigar);
                 h.pos = rb;
                 if (h.n_cigar == 0) h.type = 0;
