@@ -152,6 +152,7 @@ def main():
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--penalty", choices=["profile", "stock"], default="profile", help="full workload: PAR-CLIP error-profile costs (bwa parasuite) or stock costs (bwa aln -n 0.04)")
     ap.add_argument("--keep", default="")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: all ranks use GPU 0")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal of the N>1 path (index staged through the host)")
     args = ap.parse_args()
 
@@ -166,6 +167,8 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
+    if args.share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None

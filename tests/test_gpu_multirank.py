@@ -1,0 +1,52 @@
+"""GPU tier: the N>1 path of bench.py rehearsed with two ranks sharing the one GPU of the test box
+(gloo backend: the index blobs are staged through host memory instead of RCCL/xGMI; everything else --
+from_blobs contexts, read sharding, the chained tie-break stream -- is the code the 8-GPU run uses)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def test_two_ranks_bench_rehearsal(tmp_path):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29655", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu",
+           "--genome-mbp", "8", "--reads", "60000", "--steps", "1", "--warmup", "1", "--cpu-sample", "0"]
+    r = subprocess.run(cmd, env=env, timeout=900, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.split("\n") if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["mapped_frac"] > 0.8
+
+
+def test_sharded_batches_equal_single_batch(example, workdir):
+    """two half batches with the stream position chained == one batch (what the ranks do, in one process)"""
+    import numpy as np
+    import capi
+    import simulate as S
+    sim = S.simulate_reads(example["genome"], 3000, 50, seed=55, indel_scale=30)
+    codes = sim["codes"]
+    ctx = capi.Ctx.build(example["fa"])
+    ctx.set_stock("0.04")
+    whole = ctx.batch_from_codes(codes)
+    whole.run(4)
+    hw = whole.hits()
+    parts = []
+    before = 0
+    for a, b in ((0, 1300), (1300, 3000)):
+        sb = ctx.batch_from_codes(codes[a:b])
+        sb.search()
+        before = sb.select_hard(before)
+        sb.select_easy(4)
+        sb.locate()
+        parts.append(sb.hits())
+    hp = np.concatenate(parts)
+    for f in ("pos", "sa", "type", "strand", "mapq", "n_mm", "n_gapo", "c1", "c2", "n_cigar", "n_multi"):
+        assert np.array_equal(hw[f], hp[f]), f
+    assert (hw["c1"] > 1).sum() > 0          # some reads did need the random tie-break
