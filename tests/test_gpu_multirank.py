@@ -25,14 +25,14 @@ def test_two_ranks_bench_rehearsal(tmp_path):
     assert d["mapped_frac"] > 0.8
 
 
-def test_sharded_batches_equal_single_batch(example, workdir):
+def test_sharded_batches_equal_single_batch(multi, workdir):
     """two half batches with the stream position chained == one batch (what the ranks do, in one process)"""
     import numpy as np
     import capi
     import simulate as S
-    sim = S.simulate_reads(example["genome"], 3000, 50, seed=55, indel_scale=30)
+    sim = S.simulate_reads(multi["genome"], 3000, 50, seed=55, indel_scale=30)
     codes = sim["codes"]
-    ctx = capi.Ctx.build(example["fa"])
+    ctx = capi.Ctx.build(multi["fa"])
     ctx.set_stock("0.04")
     whole = ctx.batch_from_codes(codes)
     whole.run(4)
