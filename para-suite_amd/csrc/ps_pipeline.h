@@ -47,7 +47,7 @@ struct Ctx {
     Index ix;
     Options opt;
     int bt_blocks = 0;             // grid of the backtracking kernel (0 = 4 blocks per CU)
-    uint32_t pool_cap[3] = {8192, 65535, 2000064};   // stack entries per lane: 16-byte narrow tiers, then the wide tier
+    uint32_t pool_cap[3] = {16384, 65535, 2000064};   // stack entries per lane: 16-byte narrow tiers, then the wide tier
     int aln_cap[3] = {8, 256, 65536};
     bool want_read_iters = false; std::vector<uint32_t> read_iters;   // profiling aid: last launch's per-read iterations
     int fetch_min = 8, hit_min = 1;    // batching hits costs more in idle lanes than it saves (measured)

@@ -195,7 +195,7 @@ static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases
     if (blocks > need) blocks = need;
     // bound the lanes by stack memory (the widest tier keeps 64 MB per lane)
     const size_t per_lane = (size_t)pool_cap * (wide ? sizeof(Entry) : 16) + (wide ? PS_MAX_BUCKETS * 4 : 0);
-    const size_t max_lanes = ((size_t)(wide ? 32 : 16) << 30) / per_lane;
+    const size_t max_lanes = ((size_t)(wide ? 32 : 64) << 30) / per_lane;
     if ((size_t)blocks * 256 > max_lanes) blocks = (int)std::max<size_t>(1, max_lanes / 256);
     const int n_lanes = blocks * 256;
     uint8_t *pool = ctx->ws_get<uint8_t>("pool", (size_t)n_lanes * pool_cap * (wide ? sizeof(Entry) : 16));
