@@ -91,12 +91,20 @@ PS_HD void blk_pack(OccBlock &b, const uint8_t *syms, int n, const uint32_t cnt[
 }
 
 // register-only selects (dynamic indexing of small arrays would push them to scratch memory)
-PS_HD uint32_t sel4(const uint32_t v[4], int c) { return c == 0 ? v[0] : (c == 1 ? v[1] : (c == 2 ? v[2] : v[3])); }
-PS_HD bwtint L2_of(const IndexView &ix, int c) { return c == 0 ? ix.L2[0] : (c == 1 ? ix.L2[1] : (c == 2 ? ix.L2[2] : ix.L2[3])); }
+// two-level selects on the bits of c: three conditional moves, no branches and nothing the compiler can
+// turn back into an indexed (scratch) array
+PS_HD uint32_t sel4s(uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3, int c)
+{
+    const bool b0 = (c & 1) != 0, b1 = (c & 2) != 0;
+    const uint32_t lo = b0 ? v1 : v0, hi = b0 ? v3 : v2;
+    return b1 ? hi : lo;
+}
+PS_HD uint32_t sel4(const uint32_t v[4], int c) { return sel4s(v[0], v[1], v[2], v[3], c); }
+PS_HD bwtint L2_of(const IndexView &ix, int c) { return sel4s(ix.L2[0], ix.L2[1], ix.L2[2], ix.L2[3], c); }
 // cost of reading text symbol c where the (reverse-complemented) read has s: four byte lanes per read symbol
 PS_HD int cost_of(const uint32_t pk[5], int s, int c)
 {
-    const uint32_t w = s == 0 ? pk[0] : (s == 1 ? pk[1] : (s == 2 ? pk[2] : (s == 3 ? pk[3] : pk[4])));
+    const uint32_t w = s >= 4 ? pk[4] : sel4s(pk[0], pk[1], pk[2], pk[3], s);
     return (int)((w >> (8 * c)) & 0xffu);
 }
 
@@ -388,7 +396,7 @@ PS_HD void bt_finish_read(const BtArgs &a, BtLane &L)
 }
 
 // a hit: SA interval [k,l] reached with the current entry's edit counts (upstream bwt_match_gap's hit block)
-PS_HD void bt_hit(const BtArgs &a, BtLane &L, BtMem &m)
+PS_COLD void bt_hit(const BtArgs &a, BtLane &L, BtMem &m)
 {
     const Model &md = a.md;
     if (L.n_aln == 0) {
@@ -431,26 +439,11 @@ PS_HD void bt_hit(const BtArgs &a, BtLane &L, BtMem &m)
     out[L.n_aln++] = rec;
 }
 
-// One iteration of a lane.  fetch_r: the read this lane may take if it is idle (M_FETCH): < 0 = none offered
-// now (stay idle), >= n_reads = the input is exhausted (retire), else the read index.
-// serve_hit: lanes that reached a hit (M_HIT) record it now; the kernel batches this rare, long path over
-// several lanes of a wave instead of running it for one lane at a time.
-template <bool WIDE>
-PS_HD void bt_iter(const BtArgs &a, BtLane &L, BtMem &m, int fetch_r, bool serve_hit)
+// load one read into the lane's local memory and reset the search state; false if the read is rejected outright
+PS_COLD bool bt_fetch(const BtArgs &a, BtLane &L, BtMem &m, int fetch_r)
 {
     const Model &md = a.md;
     const int len = a.len;
-    if (L.mode == M_EXIT) return;          // retired lane: must not reach the memory step below
-    ++L.st.iters;
-    if (L.mode == M_HIT) {
-        if (!serve_hit) return;
-        L.mode = M_POP;
-        bt_hit(a, L, m);                   // may finish the read (mode becomes M_FETCH)
-        return;
-    }
-    if (L.mode == M_FETCH) {
-        if (fetch_r < 0) return;
-        if (fetch_r >= a.n_reads) { L.mode = M_EXIT; return; }
         const int r = fetch_r;
         L.r = r; L.status = RS_OK; L.n_aln = 0; L.iters0 = L.st.iters;
         // load the compact widths and the packed read into local memory (whole words, coalesced across lanes)
@@ -467,11 +460,35 @@ PS_HD void bt_iter(const BtArgs &a, BtLane &L, BtMem &m, int fetch_r, bool serve
             m.rn[p] = w;
             nNu += (int)ps_popc(w) * (int)(md.u_mm_pk[4] & 0xffu);
         }
-        if (nNu > md.max_units) { bt_finish_read(a, L); return; }
+        if (nNu > md.max_units) { bt_finish_read(a, L); return false; }
         L.k = 0; L.l = a.ix.seq_len; L.i = len; L.score = 0; L.units = 0;
         L.n_mm = L.n_gapo = L.n_gape = L.n_ins = L.n_del = 0; L.state = ST_M; L.ldp = 0;
         L.have_cur = true; L.n_stack = 0; L.bm0 = L.bm1 = 0; L.bump = 0; L.free_head = PS_NIL;
         L.best_score = 1 << 29; L.max_units = md.max_units; L.best_cnt = 0;
+        return true;
+}
+
+// One iteration of a lane.  fetch_r: the read this lane may take if it is idle (M_FETCH): < 0 = none offered
+// now (stay idle), >= n_reads = the input is exhausted (retire), else the read index.
+// serve_hit: lanes that reached a hit (M_HIT) record it now; the kernel batches this rare, long path over
+// several lanes of a wave instead of running it for one lane at a time.
+template <bool WIDE>
+PS_HD void bt_iter(const BtArgs &a, BtLane &L, BtMem &m, int fetch_r, bool serve_hit)
+{
+    const Model &md = a.md;
+    const int len = a.len;
+    if (L.mode == M_EXIT) return;          // retired lane: must not reach the memory step below
+    ++L.st.iters;
+    if (L.mode == M_HIT) {
+        if (!serve_hit) return;
+        L.mode = M_POP;
+        { BtLane t = L; bt_hit(a, t, m); L = t; }   // may finish the read (mode becomes M_FETCH)
+        return;
+    }
+    if (L.mode == M_FETCH) {
+        if (fetch_r < 0) return;
+        if (fetch_r >= a.n_reads) { L.mode = M_EXIT; return; }
+        { BtLane t = L; const bool ok = bt_fetch(a, t, m, fetch_r); L = t; if (!ok) return; }   // by-value round trip: only the copy is address-taken
         L.mode = M_POP;
     }
     if (L.mode == M_POP) {

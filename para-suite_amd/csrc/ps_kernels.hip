@@ -76,8 +76,9 @@ __global__ void __launch_bounds__(256) k_width(WidthArgs a)
 
 // ---- seed / backtracking stage --------------------------------------------
 template <bool WIDE>
-__global__ void __launch_bounds__(256) k_backtrack(BtArgs a, int lm_stride)
+__global__ void __launch_bounds__(256) k_backtrack(const BtArgs *__restrict__ ap, int lm_stride)
 {
+    const BtArgs &a = *ap;      // arguments live in device memory: the cold (non-inlined) paths take their address
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane_g = blockIdx.x * blockDim.x + threadIdx.x;
     BtMem m;
@@ -184,15 +185,16 @@ void launch_width(const WidthArgs &a, hipStream_t s)
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_width, dim3(blocks), dim3(256), 0, s, a);
 }
-void launch_backtrack(const BtArgs &a, int n_blocks, int lm_stride, hipStream_t s)
+void launch_backtrack(const BtArgs &a, const BtArgs *d_args, int n_blocks, int lm_stride, hipStream_t s)
 {
+    (void)hipMemcpyAsync(const_cast<BtArgs *>(d_args), &a, sizeof(BtArgs), hipMemcpyHostToDevice, s);
     const size_t lds = (size_t)256 * lm_stride;
     if (a.wide) {
         if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_backtrack<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_backtrack<true>, dim3(n_blocks), dim3(256), lds, s, a, lm_stride);
+        hipLaunchKernelGGL(k_backtrack<true>, dim3(n_blocks), dim3(256), lds, s, d_args, lm_stride);
     } else {
         if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_backtrack<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_backtrack<false>, dim3(n_blocks), dim3(256), lds, s, a, lm_stride);
+        hipLaunchKernelGGL(k_backtrack<false>, dim3(n_blocks), dim3(256), lds, s, d_args, lm_stride);
     }
 }
 void launch_sa2pos(const IndexView &ix, const bwtint *rows, bwtint *out, int n, KStats *stats, hipStream_t s)

@@ -211,7 +211,7 @@ static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases
     a.queue = queue; a.fetch_min = ctx->fetch_min; a.hit_min = ctx->hit_min;
     uint32_t *riters = nullptr;
     if (ctx->want_read_iters) { riters = ctx->ws_get<uint32_t>("riters", n); PS_HIP(hipMemsetAsync(riters, 0, (size_t)n * 4, s)); a.read_iters = riters; }
-    { EvTimer t(s); launch_backtrack(a, blocks, lm, s); PS_HIP(hipGetLastError()); b.tm.ms_backtrack += t.stop(); ++b.tm.n_backtrack_launches; }
+    { EvTimer t(s); launch_backtrack(a, ctx->ws_get<BtArgs>("btargs", 1), blocks, lm, s); PS_HIP(hipGetLastError()); b.tm.ms_backtrack += t.stop(); ++b.tm.n_backtrack_launches; }
     // compact the hit lists on the device, then one download through pinned staging
     EvTimer tc(s);
     uint32_t *cnt = ctx->ws_get<uint32_t>("cnt", n), *off = ctx->ws_get<uint32_t>("off", (size_t)n + 1);
@@ -220,7 +220,9 @@ static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases
     PS_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, cnt, off, n, s));
     uint8_t *tmp = ctx->ws_get<uint8_t>("scan_tmp", tb ? tb : 1);
     PS_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tb, cnt, off, n, s));
-    if (ctx->want_read_iters) { ctx->read_iters.resize(n); PS_HIP(hipMemcpyAsync(ctx->read_iters.data(), riters, (size_t)n * 4, hipMemcpyDeviceToHost, s)); }
+    if (ctx->want_read_iters) {
+        ctx->read_iters.resize(n); PS_HIP(hipMemcpyAsync(ctx->read_iters.data(), riters, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    }
     int32_t *p_na = (int32_t *)out.pn->get((size_t)n * 4 + 64); uint8_t *p_st = (uint8_t *)out.ps->get((size_t)n + 64);
     uint32_t *p_off = (uint32_t *)out.po->get(((size_t)n + 1) * 4 + 64);
     PS_HIP(hipMemcpyAsync(p_na, n_aln, (size_t)n * 4, hipMemcpyDeviceToHost, s));

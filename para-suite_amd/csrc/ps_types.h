@@ -10,8 +10,11 @@
 
 #ifdef __HIPCC__
 #define PS_HD __host__ __device__ __forceinline__
+#define PS_COLD __host__ __device__ __attribute__((noinline))   // rare, long paths: real calls keep their
+                                                                // scalars out of the hot loop's register budget
 #else
 #define PS_HD inline
+#define PS_COLD inline
 #endif
 
 namespace ps {
