@@ -10,7 +10,7 @@
 
 #ifdef __HIPCC__
 #define PS_HD __host__ __device__ __forceinline__
-#define PS_COLD __host__ __device__ __attribute__((noinline))   // rare, long paths: real calls keep their
+#define PS_COLD __host__ __device__ inline __attribute__((noinline))   // rare, long paths: real calls keep their
                                                                 // scalars out of the hot loop's register budget
 #else
 #define PS_HD inline
