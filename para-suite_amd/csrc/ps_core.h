@@ -312,14 +312,16 @@ PS_HD void load_entry(const Entry *src, Entry &e)
 #endif
 }
 
-// push a child entry on its score bucket (LIFO linked list through the entries' next field)
+// push a child entry on its score bucket (LIFO linked list through the entries' next field).  `want` is the
+// caller's condition for this child: the narrow path is written with selects and ONE predicated region,
+// because every taken branch costs a divergent wave far more than a few masked instructions.
 template <bool WIDE>
-PS_HD void bt_push(const BtArgs &a, BtLane &L, BtMem &m, int i, bwtint k, bwtint l, int n_mm, int n_gapo, int n_gape,
+PS_HD void bt_push(const BtArgs &a, BtLane &L, BtMem &m, bool want, int i, bwtint k, bwtint l, int n_mm, int n_gapo, int n_gape,
                    int n_ins, int n_del, int state, bool is_diff, int score, int units)
 {
-    if (units > L.max_units) return;        // cannot be afforded (no-op with stock costs)
-    if (score >= a.md.n_buckets) { L.status = RS_BAD_SCORE; return; }   // cannot happen (make_model sizes the buckets); never write past the heads
     if (WIDE) {
+        if (!want || units > L.max_units) return;        // unaffordable children are not pushed (no-op with stock costs)
+        if (score >= a.md.n_buckets) { L.status = RS_BAD_SCORE; return; }
         Entry *pool = reinterpret_cast<Entry *>(m.pool);
         uint32_t idx;
         if (L.free_head != PS_NIL) { idx = L.free_head; L.free_head = pool[idx].next; }
@@ -334,23 +336,36 @@ PS_HD void bt_push(const BtArgs &a, BtLane &L, BtMem &m, int i, bwtint k, bwtint
         e.pad[0] = e.pad[1] = 0;
         store_entry(&pool[idx], e);
         m.heads[score] = idx;
+        bm_set(L, score);
+        ++L.n_stack; ++L.st.pushes;
     } else {
-        // the slot of the entry popped last is reused first (no free list to maintain), then fresh slots
-        uint32_t idx = L.free_head;
-        if (idx != PS_NIL) L.free_head = PS_NIL;
-        else if (L.bump < a.pool_cap) idx = L.bump++;
-        else { L.status = RS_OVERFLOW_POOL; return; }
-        const uint32_t next = bm_test(L, score) ? (uint32_t)m.heads16[score] : PS_NIL16;
-        Entry16 e;
-        e.k = k; e.l = l;
-        e.a = (uint32_t)i | ((uint32_t)(is_diff ? i : 0) << 8) | ((uint32_t)n_mm << 16) |
-              (((uint32_t)state | ((uint32_t)n_gapo << 2) | ((uint32_t)n_gape << 5)) << 24);
-        e.b = (uint32_t)n_ins | ((uint32_t)n_del << 4) | ((uint32_t)score << 8) | (next << 16);
-        store16(reinterpret_cast<Entry16 *>(m.pool) + idx, e);
-        m.heads16[score] = (uint16_t)idx;
+        const bool afford = want && units <= L.max_units;              // unaffordable children are not pushed
+        const bool in_range = score < a.md.n_buckets;                   // always true (make_model sizes the buckets); guards the heads
+        const bool reuse = L.free_head != PS_NIL;                       // the slot of the entry popped last is reused first
+        const bool have_slot = reuse || L.bump < a.pool_cap;
+        const bool go = afford && in_range && have_slot;
+        L.status = (afford && !in_range) ? RS_BAD_SCORE : ((afford && in_range && !have_slot) ? RS_OVERFLOW_POOL : L.status);
+        const uint32_t idx = reuse ? L.free_head : L.bump;
+        const unsigned long long bit = 1ull << (score & 63);
+        const bool hi = (score & 64) != 0;
+        if (go) {
+            const bool nonempty = ((hi ? L.bm1 : L.bm0) & bit) != 0;
+            const uint32_t next = nonempty ? (uint32_t)m.heads16[score] : PS_NIL16;
+            Entry16 e;
+            e.k = k; e.l = l;
+            e.a = (uint32_t)i | ((uint32_t)(is_diff ? i : 0) << 8) | ((uint32_t)n_mm << 16) |
+                  (((uint32_t)state | ((uint32_t)n_gapo << 2) | ((uint32_t)n_gape << 5)) << 24);
+            e.b = (uint32_t)n_ins | ((uint32_t)n_del << 4) | ((uint32_t)score << 8) | (next << 16);
+            store16(reinterpret_cast<Entry16 *>(m.pool) + idx, e);
+            m.heads16[score] = (uint16_t)idx;
+        }
+        L.bm0 |= (go && !hi) ? bit : 0ull;
+        L.bm1 |= (go && hi) ? bit : 0ull;
+        L.free_head = go ? PS_NIL : L.free_head;
+        L.bump += (go && !reuse) ? 1u : 0u;
+        L.n_stack += go ? 1 : 0;
+        L.st.pushes += go ? 1u : 0u;
     }
-    bm_set(L, score);
-    ++L.n_stack; ++L.st.pushes;
 }
 
 // pop the newest entry of the lowest non-empty score bucket into the lane's current-entry registers
@@ -560,19 +575,19 @@ PS_HD void bt_iter(const BtArgs &a, BtLane &L, BtMem &m, int fetch_r, bool serve
         if (allow_diff && i >= md.indel_end_skip + tmp && len - i >= md.indel_end_skip + tmp) {
             if (e_st == ST_M) {
                 if (e_go < md.max_gapo) {
-                    bt_push<WIDE>(a, L, m, i, ek, el, e_mm, e_go + 1, e_ge, e_ni + 1, e_nd, ST_I, true, e_sc + md.s_gapo_ins, e_un + md.u_gapo_ins);
+                    bt_push<WIDE>(a, L, m, true, i, ek, el, e_mm, e_go + 1, e_ge, e_ni + 1, e_nd, ST_I, true, e_sc + md.s_gapo_ins, e_un + md.u_gapo_ins);
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        if (nk[j] <= nl[j]) bt_push<WIDE>(a, L, m, i + 1, nk[j], nl[j], e_mm, e_go + 1, e_ge, e_ni, e_nd + 1, ST_D, true, e_sc + md.s_gapo_del, e_un + md.u_gapo_del);
+                        bt_push<WIDE>(a, L, m, nk[j] <= nl[j], i + 1, nk[j], nl[j], e_mm, e_go + 1, e_ge, e_ni, e_nd + 1, ST_D, true, e_sc + md.s_gapo_del, e_un + md.u_gapo_del);
                 }
             } else if (e_st == ST_I) {
                 if (e_ge < md.max_gape)
-                    bt_push<WIDE>(a, L, m, i, ek, el, e_mm, e_go, e_ge + 1, e_ni + 1, e_nd, ST_I, true, e_sc + md.s_gape, e_un + md.u_gape);
+                    bt_push<WIDE>(a, L, m, true, i, ek, el, e_mm, e_go, e_ge + 1, e_ni + 1, e_nd, ST_I, true, e_sc + md.s_gape, e_un + md.u_gape);
             } else {
                 if (e_ge < md.max_gape && ((e_ge + e_go) * md.u_tight < L.max_units || occ < (bwtint)md.max_del_occ)) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        if (nk[j] <= nl[j]) bt_push<WIDE>(a, L, m, i + 1, nk[j], nl[j], e_mm, e_go, e_ge + 1, e_ni, e_nd + 1, ST_D, true, e_sc + md.s_gape, e_un + md.u_gape);
+                        bt_push<WIDE>(a, L, m, nk[j] <= nl[j], i + 1, nk[j], nl[j], e_mm, e_go, e_ge + 1, e_ni, e_nd + 1, ST_D, true, e_sc + md.s_gape, e_un + md.u_gape);
                 }
             }
         }
@@ -583,9 +598,9 @@ PS_HD void bt_iter(const BtArgs &a, BtLane &L, BtMem &m, int fetch_r, bool serve
                 const int c = (s + j) & 3;
                 const bool is_mm = (j != 4 || s > 3);
                 const bwtint k2 = sel4(nk, c), l2 = sel4(nl, c);
-                if (k2 > l2) continue;
-                if (is_mm) bt_push<WIDE>(a, L, m, i, k2, l2, e_mm + 1, e_go, e_ge, e_ni, e_nd, ST_M, true, e_sc + cost_of(md.s_mm_pk, s, c), e_un + cost_of(md.u_mm_pk, s, c));
-                else { // the match child has the parent's score and is pushed last: it is the next pop
+                const bool ok = k2 <= l2;
+                bt_push<WIDE>(a, L, m, ok && is_mm, i, k2, l2, e_mm + 1, e_go, e_ge, e_ni, e_nd, ST_M, true, e_sc + cost_of(md.s_mm_pk, s, c), e_un + cost_of(md.u_mm_pk, s, c));
+                if (ok && !is_mm) { // the match child has the parent's score and is pushed last: it is the next pop
                     L.k = k2; L.l = l2; L.i = i; L.state = ST_M; L.ldp = 0; L.have_cur = true;
                 }
             }

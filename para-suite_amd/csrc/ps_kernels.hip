@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(256) k_width(WidthArgs a)
 
 // ---- seed / backtracking stage --------------------------------------------
 template <bool WIDE>
-__global__ void __launch_bounds__(256, 2) k_backtrack(const BtArgs *__restrict__ ap, int lm_stride)
+__global__ void __launch_bounds__(256) k_backtrack(const BtArgs *__restrict__ ap, int lm_stride)
 {
     const BtArgs &a = *ap;      // arguments live in device memory: the cold (non-inlined) paths take their address
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
