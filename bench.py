@@ -235,11 +235,19 @@ def main():
 
     chain = torch.zeros(1, dtype=torch.int64, device=dev if args.backend == "nccl" else "cpu")
 
+    wall = {"search": 0.0, "select_hard": 0.0, "select_easy": 0.0, "locate": 0.0}
+
     def step():
+        t0 = time.perf_counter()
         batch.search()
+        t1 = time.perf_counter()
         sharding.chain_stream_position(dist, rank, world, chain, batch.select_hard)   # tie-break stream handed down the ranks
+        t2 = time.perf_counter()
         batch.select_easy(threads)
+        t3 = time.perf_counter()
         batch.locate()
+        t4 = time.perf_counter()
+        wall["search"] += t1 - t0; wall["select_hard"] += t2 - t1; wall["select_easy"] += t3 - t2; wall["locate"] += t4 - t3
 
     def sync():
         torch.cuda.synchronize()
@@ -250,6 +258,8 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
+    for k in wall:
+        wall[k] = 0.0
     acc = {}
     t_start = time.perf_counter()
     for _ in range(args.steps):
@@ -301,6 +311,7 @@ def main():
                          "width_kernel": {"achieved": alg_w / (ms_w_step * 1e-3) / 1e9, "frac": alg_w / (ms_w_step * 1e-3) / 1e9 / 8000.0}},
             "kernels_ms_per_step": {k: acc[k] / K for k in ("ms_width", "ms_backtrack", "ms_compact", "ms_select", "ms_sa2pos",
                                                             "ms_refine", "ms_host_post", "ms_classify", "ms_rows", "ms_sel_hard", "ms_sel_easy")},
+            "stage_wall_ms_per_step": {k: 1e3 * v / K for k, v in wall.items()},
             "kstats": {"backtrack": ks_bt, "width": ks_w, "sa2pos": ks_sa},
             "mapped_frac": float((hits["type"] != 0).mean()),
             "overflow_reads": [int(acc["n_overflow_tier1"] / K), int(acc["n_overflow_tier2"] / K)],

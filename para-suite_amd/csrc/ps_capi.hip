@@ -232,7 +232,7 @@ int ps_batch_hits(ps_batch *b, ps_hit *out, int64_t cap)
     PS_TRY
         Batch &B = *b->b;
         for (int64_t g = 0; g < B.rs.n && g < cap; ++g) {
-            const Hit &h = B.hits[g]; ps_hit &o = out[g];
+            Hit h; B.hit_of(g, h); ps_hit &o = out[g];
             o.pos = h.type ? h.pos : -1; o.sa = h.sa; o.type = h.type; o.strand = h.strand; o.mapq = h.mapq; o.n_mm = h.n_mm; o.n_gapo = h.n_gapo;
             o.n_gape = h.n_gape; o.ref_shift = h.ref_shift; o.score = h.score; o.c1 = h.c1; o.c2 = h.c2; o.n_cigar = h.n_cigar; o.n_multi = h.n_multi;
             std::memset(o.cigar, 0, sizeof o.cigar); std::memcpy(o.cigar, h.cigar, sizeof h.cigar);

@@ -27,6 +27,13 @@ struct Hit {
     uint32_t cigar[PS_HIT_CIGAR];    // gapped main hits with more operations are rejected (needs max_gapo > 2)
 };
 
+// per-read records of the samse stage for reads finished on the device
+struct SelRec { bwtint sa; int32_t c1, c2; uint8_t type, n_mm, n_gapo, n_gape; int8_t ref_shift; uint8_t score, pad[2]; };   // 20 B
+struct FinRec { int64_t pos; uint8_t strand, mapq, type, pad[5]; };                                                        // 16 B
+struct DevCigar { int64_t g; int32_t n; uint32_t c[PS_HIT_CIGAR]; };
+// a read finished on the host: several best-score intervals (sequential tie-break), alternative hits, or a larger tier
+struct SubRead { int64_t g = 0, easy_before = 0, hard_before = 0; uint8_t cls = 0; std::vector<AlnRec> alns; Hit hit; };
+
 struct Timing {
     double ms_width = 0, ms_backtrack = 0, ms_compact = 0, ms_select = 0, ms_sa2pos = 0, ms_refine = 0, ms_host_post = 0, ms_total = 0, ms_classify = 0, ms_rows = 0, ms_sel_hard = 0, ms_sel_easy = 0;
     int n_width_launches = 0, n_backtrack_launches = 0;
@@ -69,9 +76,10 @@ struct Bin {
     std::vector<int32_t> ids;                 // global read index of every local read
     DevBuf<uint32_t> bases, nmask, w; DevBuf<uint8_t> cwb, cswb, status; DevBuf<AlnRec> alns; DevBuf<int32_t> n_aln;
     std::vector<uint32_t> h_bases, h_nmask;   // host copy (tier re-runs gather from it)
-    // compact hit lists of the first search tier, downloaded straight into page-locked memory owned by the bin
-    std::shared_ptr<PinBuf> pin_n_aln, pin_status, pin_off, pin_alns;
-    int32_t *h_n_aln = nullptr; uint32_t *h_off = nullptr; AlnRec *h_alns = nullptr;
+    DevBuf<int32_t> d_ids;                     // ids on the device (bin-local -> input order)
+    DevBuf<AlnRec> d_alns; DevBuf<int32_t> d_n_aln; DevBuf<uint8_t> d_status; int aln_cap = 0;   // first-tier hit lists stay in HBM
+    bool host_alns_valid = false;             // compact host copy, downloaded on demand (tests, ps_batch_alns)
+    std::vector<int32_t> h_n_aln; std::vector<uint32_t> h_off; std::vector<AlnRec> h_alns;
     std::map<int32_t, std::vector<AlnRec>> overflow;                                          // reads that needed a larger tier
     int n_bw = 0, n_mw = 0;
 };
@@ -81,18 +89,21 @@ struct Batch {
     ReadSet rs;
     std::vector<Bin> bins;
     std::vector<int32_t> read_bin, read_local;
-    std::vector<Hit> hits; std::vector<Multi> multis;
-    // RNG bookkeeping for the tie-break stream (one sequential drand48 stream over reads)
-    std::vector<uint8_t> n_best;           // leading hits with the best score (saturated at 255)
-    std::vector<int64_t> hard;             // global indices of reads with >= 2 best hits
-    std::vector<uint64_t> hard_draws_cum;  // draws consumed by hard reads up to and including this one
-    std::vector<int64_t> easy_before;      // per hard read: mapped single-best reads before it
-    int64_t n_easy = 0; uint64_t draws_in = 0, draws_out = 0;
+    // samse stage: classes and device records in input order; the host-finished subset
+    DevBuf<uint8_t> d_class; DevBuf<uint32_t> d_eb, d_hb; DevBuf<bwtint> d_rows, d_pos; DevBuf<SelRec> d_sel; DevBuf<FinRec> d_fin;
+    PinBuf p_class, p_sel, p_fin;
+    uint8_t *h_class = nullptr; SelRec *h_sel = nullptr; FinRec *h_fin = nullptr;
+    std::vector<SubRead> sub; std::vector<Multi> multis; std::vector<DevCigar> dev_cigars;
+    int64_t n_class1 = 0, n_hard = 0;
+    std::vector<uint64_t> hard_draws_cum;  // draws consumed by the several-best reads up to and including each
+    uint64_t draws_in = 0, draws_out = 0;
     DevBuf<KStats> d_stats; KStats st_width{}, st_backtrack{}, st_sa2pos{};
     Timing tm;
     int64_t n_overflow[3] = {0, 0, 0};
     bool searched = false, selected_hard = false, selected = false, located = false;
-    const AlnRec *alns_of(int64_t g, int &n) const;
+    const AlnRec *alns_of(int64_t g, int &n);      // downloads the hit lists on first use
+    void ensure_host_alns();
+    void hit_of(int64_t g, Hit &h) const;
 };
 
 std::unique_ptr<Batch> batch_create(Ctx *ctx, ReadSet &&rs);   // bins by length, packs 2-bit, uploads

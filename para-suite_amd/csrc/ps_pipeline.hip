@@ -135,6 +135,7 @@ std::unique_ptr<Batch> batch_create(Ctx *ctx, ReadSet &&rs_in)
                 else bin.h_bases[(size_t)(j >> 4) * n + r] |= (uint32_t)s[j] << (2 * (j & 15));
             }
         }
+        bin.d_ids.alloc(n); bin.d_ids.upload(bin.ids.data(), n, ctx->stream);
         bin.bases.alloc(bin.h_bases.size()); bin.nmask.alloc(bin.h_nmask.size());
         bin.bases.upload(bin.h_bases.data(), bin.h_bases.size(), ctx->stream);
         bin.nmask.upload(bin.h_nmask.data(), bin.h_nmask.size(), ctx->stream);
@@ -164,21 +165,16 @@ struct EvTimer {
     ~EvTimer() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
 };
 
-// results of one search launch; the buffers are page-locked and owned by the caller
-struct SearchOut { PinBuf *pn, *ps, *po, *pa; int32_t *n_aln; uint8_t *status; uint32_t *off; AlnRec *alns; };
 
 // width + backtracking kernels over n reads of one length that are already packed on the device
 static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases, const uint32_t *d_nmask,
-                       uint32_t pool_cap, int aln_cap, SearchOut &out)
+                       uint32_t pool_cap, int aln_cap, AlnRec *alns, int32_t *n_aln, uint8_t *status)
 {
     Ctx *ctx = b.ctx; hipStream_t s = ctx->stream;
     const int len = md.len, seed_len = md.seed_len;
     uint32_t *w = ctx->ws_get<uint32_t>("w", (size_t)(len + 1) * n);
     uint32_t *cwb = ctx->ws_get<uint32_t>("cwb", (size_t)lm_ncw(len) * n);
     uint32_t *cswb = ctx->ws_get<uint32_t>("cswb", (size_t)(lm_ncsw(seed_len) + 1) * n);
-    uint8_t *status = ctx->ws_get<uint8_t>("status", n);
-    AlnRec *alns = ctx->ws_get<AlnRec>("alns", (size_t)n * aln_cap);
-    int32_t *n_aln = ctx->ws_get<int32_t>("n_aln", n);
     WidthArgs wa;
     wa.ix = ctx->ix.view; wa.n_reads = n; wa.len = len; wa.seed_len = seed_len; wa.use_seed = md.use_seed;
     wa.bases = d_bases; wa.nmask = d_nmask; wa.w = w; wa.cwb = cwb; wa.cswb = cswb; wa.stats = b.d_stats.p + 0;
@@ -212,59 +208,204 @@ static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases
     uint32_t *riters = nullptr;
     if (ctx->want_read_iters) { riters = ctx->ws_get<uint32_t>("riters", n); PS_HIP(hipMemsetAsync(riters, 0, (size_t)n * 4, s)); a.read_iters = riters; }
     { EvTimer t(s); launch_backtrack(a, ctx->ws_get<BtArgs>("btargs", 1), blocks, lm, s); PS_HIP(hipGetLastError()); b.tm.ms_backtrack += t.stop(); ++b.tm.n_backtrack_launches; }
-    // compact the hit lists on the device, then one download through pinned staging
-    EvTimer tc(s);
-    uint32_t *cnt = ctx->ws_get<uint32_t>("cnt", n), *off = ctx->ws_get<uint32_t>("off", (size_t)n + 1);
-    hipLaunchKernelGGL(k_clip_counts, dim3((n + 255) / 256), dim3(256), 0, s, n_aln, aln_cap, n, cnt);
+    if (ctx->want_read_iters) { ctx->read_iters.resize(n); PS_HIP(hipMemcpyAsync(ctx->read_iters.data(), riters, (size_t)n * 4, hipMemcpyDeviceToHost, s)); PS_HIP(hipStreamSynchronize(s)); }
+}
+
+// ------------------------------------------------------------- host helpers ------
+// download the hit lists of n reads (stride aln_cap on the device) in compact form
+static void download_alns(Ctx *ctx, int n, int aln_cap, const AlnRec *d_alns, const int32_t *d_n_aln,
+                          std::vector<int32_t> &n_aln, std::vector<uint32_t> &off, std::vector<AlnRec> &alns)
+{
+    hipStream_t s = ctx->stream;
+    uint32_t *cnt = ctx->ws_get<uint32_t>("cnt", n), *d_off = ctx->ws_get<uint32_t>("off", (size_t)n + 1);
+    hipLaunchKernelGGL(k_clip_counts, dim3((n + 255) / 256), dim3(256), 0, s, d_n_aln, aln_cap, n, cnt);
     size_t tb = 0;
-    PS_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, cnt, off, n, s));
+    PS_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, cnt, d_off, n, s));
     uint8_t *tmp = ctx->ws_get<uint8_t>("scan_tmp", tb ? tb : 1);
-    PS_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tb, cnt, off, n, s));
-    if (ctx->want_read_iters) {
-        ctx->read_iters.resize(n); PS_HIP(hipMemcpyAsync(ctx->read_iters.data(), riters, (size_t)n * 4, hipMemcpyDeviceToHost, s));
-    }
-    int32_t *p_na = (int32_t *)out.pn->get((size_t)n * 4 + 64); uint8_t *p_st = (uint8_t *)out.ps->get((size_t)n + 64);
-    uint32_t *p_off = (uint32_t *)out.po->get(((size_t)n + 1) * 4 + 64);
-    PS_HIP(hipMemcpyAsync(p_na, n_aln, (size_t)n * 4, hipMemcpyDeviceToHost, s));
-    PS_HIP(hipMemcpyAsync(p_st, status, (size_t)n, hipMemcpyDeviceToHost, s));
-    PS_HIP(hipMemcpyAsync(p_off, off, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    PS_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tb, cnt, d_off, n, s));
+    int32_t *p_na = ctx->pin_get<int32_t>("dl_n_aln", n); uint32_t *p_off = ctx->pin_get<uint32_t>("dl_off", (size_t)n + 1);
+    PS_HIP(hipMemcpyAsync(p_na, d_n_aln, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    PS_HIP(hipMemcpyAsync(p_off, d_off, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     PS_HIP(hipStreamSynchronize(s));
     uint32_t last = 0;
     if (n) { int m = p_na[n - 1]; last = p_off[n - 1] + (uint32_t)(m > aln_cap ? aln_cap : (m < 0 ? 0 : m)); }
     p_off[n] = last;
-    AlnRec *p_al = (AlnRec *)out.pa->get((size_t)last * sizeof(AlnRec) + 64);
+    n_aln.assign(p_na, p_na + n); off.assign(p_off, p_off + n + 1); alns.resize(last);
     if (last) {
         AlnRec *comp = ctx->ws_get<AlnRec>("comp", last);
-        hipLaunchKernelGGL(k_gather_alns, dim3((n + 255) / 256), dim3(256), 0, s, alns, aln_cap, n_aln, off, n, comp);
+        hipLaunchKernelGGL(k_gather_alns, dim3((n + 255) / 256), dim3(256), 0, s, d_alns, aln_cap, d_n_aln, d_off, n, comp);
+        AlnRec *p_al = ctx->pin_get<AlnRec>("dl_alns", last);
         PS_HIP(hipMemcpyAsync(p_al, comp, (size_t)last * sizeof(AlnRec), hipMemcpyDeviceToHost, s));
         PS_HIP(hipStreamSynchronize(s));
+        std::memcpy(alns.data(), p_al, (size_t)last * sizeof(AlnRec));
     }
-    out.n_aln = p_na; out.status = p_st; out.off = p_off; out.alns = p_al;
-    b.tm.ms_compact += tc.stop();
 }
 
+// ------------------------------------------------- samse stage on the device --------
+// Read classes for the tie-break stream (one drand48 stream over all reads in input order):
+//   0 no hit (no draw) | 1 exactly one best-score SA interval (always two draws) | 2 several (data dependent)
+// bit 2 (PS_CLS_HOST): the read is finished on the host -- class 2 (sequential chain), reads that list
+// alternative hits (XA), reads that needed a larger search tier.  Everything else never leaves the GPU.
+static const uint8_t PS_CLS_HOST = 4;
+
+__global__ void k_classify(const AlnRec *alns, int aln_cap, const int32_t *n_aln, const uint8_t *status, const int32_t *ids,
+                           int n, int n_occ, uint8_t *cls_out)
+{
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+        uint8_t c = 0;
+        if (status[r] != RS_OK) c = 3 | PS_CLS_HOST;        // hit list lives on the host (larger tier): class fixed there
+        else {
+            const int na = n_aln[r];
+            if (na > 0) {
+                const AlnRec *al = alns + (size_t)r * aln_cap;
+                const int best = al[0].score;
+                int nb = 0; unsigned long long tot = 0;
+                for (int j = 0; j < na; ++j) { if (al[j].score == best && nb == j) ++nb; tot += (unsigned long long)(al[j].l - al[j].k) + 1ull; }
+                c = nb == 1 ? 1 : 2;
+                if (c == 2 || (n_occ > 0 && tot >= 2 && tot <= (unsigned long long)n_occ + 1ull)) c |= PS_CLS_HOST;
+            }
+        }
+        cls_out[ids[r]] = c;
+    }
+}
+__global__ void k_class_flags(const uint8_t *cls, long long n, uint32_t *is1, uint32_t *is2)
+{
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
+        const int c = cls[g] & 3;
+        is1[g] = c == 1; is2[g] = c == 2;
+    }
+}
+__global__ void k_gather_sub(const AlnRec *alns, int aln_cap, const int32_t *n_aln, const int32_t *local, int m, AlnRec *out, int32_t *n_out)
+{
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < m; q += gridDim.x * blockDim.x) {
+        const int r = local[q]; int na = n_aln[r]; if (na > aln_cap) na = aln_cap;
+        n_out[q] = na;
+        for (int j = 0; j < na; ++j) out[(size_t)q * aln_cap + j] = alns[(size_t)r * aln_cap + j];
+    }
+}
+
+__device__ __forceinline__ unsigned long long lcg_jump(unsigned long long x, unsigned long long t)
+{
+    const unsigned long long M = 0xFFFFFFFFFFFFULL;
+    unsigned long long a = 0x5DEECE66DULL, c = 0xBULL, ra = 1, rc = 0;
+    while (t) {
+        if (t & 1) { ra = (ra * a) & M; rc = (rc * a + c) & M; }
+        c = (c * a + c) & M; a = (a * a) & M;
+        t >>= 1;
+    }
+    return (ra * x + rc) & M;
+}
+
+struct SelectArgs {
+    const AlnRec *alns; int aln_cap; const int32_t *n_aln; const int32_t *ids; int n;
+    const uint8_t *cls; const uint32_t *e_before; const uint32_t *h_before; const unsigned long long *hard_cum;
+    unsigned long long draws_in;
+    SelRec *sel; bwtint *rows; int *err;
+};
+// the single-best reads: two draws at a stream position known from the prefix counts
+__global__ void k_select(SelectArgs a)
+{
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < a.n; r += gridDim.x * blockDim.x) {
+        const int g = a.ids[r];
+        const uint8_t c = a.cls[g];
+        SelRec s; s.sa = 0; s.c1 = s.c2 = 0; s.type = 0; s.n_mm = s.n_gapo = s.n_gape = 0; s.ref_shift = 0; s.score = 0; s.pad[0] = s.pad[1] = 0;
+        if (c == 1) {                       // class 1, finished on the device
+            const AlnRec *al = a.alns + (size_t)r * a.aln_cap;
+            const int na = a.n_aln[r];
+            const unsigned int hb = a.h_before[g];
+            const unsigned long long off = a.draws_in + 2ull * a.e_before[g] + (hb ? a.hard_cum[hb - 1] : 0ull);
+            unsigned long long x = lcg_jump((11ull << 16) | 0x330Eull, off);
+            x = (x * 0x5DEECE66DULL + 0xBULL) & 0xFFFFFFFFFFFFULL;            // first draw: r*w > 0 unless the state is 0
+            if (x == 0) *a.err = 1;
+            x = (x * 0x5DEECE66DULL + 0xBULL) & 0xFFFFFFFFFFFFULL;            // second draw places the hit inside its interval
+            const AlnRec p = al[0];
+            const unsigned long long wdt = (unsigned long long)(p.l - p.k) + 1ull;
+            const double r2 = (double)x * (1.0 / 281474976710656.0);
+            s.sa = p.k + (bwtint)((double)wdt * r2);
+            int cnt = (int)wdt;
+            s.c1 = cnt;
+            for (int j = 1; j < na; ++j) cnt += (int)((unsigned long long)(al[j].l - al[j].k) + 1ull);
+            s.c2 = cnt - s.c1;
+            s.type = s.c1 > 1 ? 2 : 1;
+            s.n_mm = p.n_mm; s.n_gapo = p.n_gapo; s.n_gape = p.n_gape; s.ref_shift = (int8_t)((int)p.n_del - (int)p.n_ins); s.score = (uint8_t)p.score;
+        }
+        a.sel[g] = s;
+        a.rows[g] = s.type ? s.sa : 0;
+    }
+}
+
+struct PostArgs {
+    const int32_t *ids; int n, len; long long l_pac;
+    const uint8_t *cls; const SelRec *sel; const bwtint *pos; FinRec *fin;
+    int budget, profile, unit; const uint8_t *logn;     // MAPQ rule inputs; logn[n] = (int)(4.343 ln n + .5)
+    RefineItem *items; int32_t *item_g; unsigned int *n_items;
+};
+// text position -> forward coordinate + strand, MAPQ; gapped hits are queued for the banded-DP kernel
+__global__ void k_post(PostArgs a)
+{
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < a.n; r += gridDim.x * blockDim.x) {
+        const int g = a.ids[r];
+        FinRec f; f.pos = -1; f.strand = 0; f.mapq = 0; f.type = 0; f.pad[0] = f.pad[1] = f.pad[2] = f.pad[3] = f.pad[4] = 0;
+        const SelRec s = a.sel[g];
+        if (a.cls[g] == 1 && s.type != 0) {
+            long long pos_f = (long long)a.pos[g];
+            const int ref_len = a.len + s.ref_shift;
+            int strand = 0; long long p = -1;
+            if (!(pos_f < a.l_pac && a.l_pac < pos_f + ref_len)) {
+                const bool is_rev = pos_f >= a.l_pac;
+                if (is_rev) pos_f = 2 * a.l_pac - 1 - pos_f;
+                strand = !is_rev;
+                if (is_rev) pos_f = pos_f + 1 < ref_len ? 0 : pos_f - ref_len + 1;
+                p = pos_f;
+            }
+            int mq;
+            if (s.c1 == 0) mq = 23;
+            else if (s.c1 > 1) mq = 0;
+            else if (!a.profile && s.n_mm == a.budget) mq = 25;
+            else if (a.profile && a.budget * a.unit - (int)s.score < a.unit) mq = 25;
+            else if (s.c2 == 0) mq = 37;
+            else { const int nn = s.c2 >= 255 ? 255 : s.c2; const int lg = a.logn[nn]; mq = 23 < lg ? 0 : 23 - lg; }
+            f.pos = p; f.strand = (uint8_t)strand; f.mapq = (uint8_t)mq; f.type = p < 0 ? 0 : s.type;
+            if (f.type != 0 && s.n_gapo) {
+                const unsigned int q = atomicAdd(a.n_items, 1u);
+                a.items[q] = RefineItem{r, (bwtint)p, (int32_t)s.ref_shift, strand};
+                a.item_g[q] = g;
+            }
+        }
+        a.fin[g] = f;
+    }
+}
+
+// --------------------------------------------------------------- search stage -------
 void batch_search(Batch &b)
 {
-    Ctx *ctx = b.ctx;
+    Ctx *ctx = b.ctx; hipStream_t s = ctx->stream;
     require_device(ctx->device);
     b.tm = Timing();
     auto t0 = Clock::now();
-    b.d_stats.zero(ctx->stream);
+    const int64_t N = b.rs.n;
+    b.d_stats.zero(s);
     for (int t = 0; t < 3; ++t) b.n_overflow[t] = 0;
+    if (b.d_class.n < (size_t)N) b.d_class.alloc((size_t)N);
     for (Bin &bin : b.bins) {
         const int n = (int)bin.ids.size();
-        if (!bin.pin_n_aln) { bin.pin_n_aln.reset(new PinBuf()); bin.pin_status.reset(new PinBuf()); bin.pin_off.reset(new PinBuf()); bin.pin_alns.reset(new PinBuf()); }
-        SearchOut so{bin.pin_n_aln.get(), bin.pin_status.get(), bin.pin_off.get(), bin.pin_alns.get(), nullptr, nullptr, nullptr, nullptr};
-        run_search(b, bin.md, n, bin.bases.p, bin.nmask.p, ctx->pool_cap[0], ctx->aln_cap[0], so);
-        bin.h_n_aln = so.n_aln; bin.h_off = so.off; bin.h_alns = so.alns;
+        bin.host_alns_valid = false;
+        if (bin.d_alns.n < (size_t)n * ctx->aln_cap[0]) { bin.d_alns.alloc((size_t)n * ctx->aln_cap[0]); bin.d_n_aln.alloc(n); bin.d_status.alloc(n); }
+        bin.aln_cap = ctx->aln_cap[0];
+        run_search(b, bin.md, n, bin.bases.p, bin.nmask.p, ctx->pool_cap[0], bin.aln_cap, bin.d_alns.p, bin.d_n_aln.p, bin.d_status.p);
+        uint8_t *h_status = ctx->pin_get<uint8_t>("status", n);
+        PS_HIP(hipMemcpyAsync(h_status, bin.d_status.p, (size_t)n, hipMemcpyDeviceToHost, s));
+        hipLaunchKernelGGL(k_classify, dim3(std::min((n + 255) / 256, 4096)), dim3(256), 0, s, bin.d_alns.p, bin.aln_cap, bin.d_n_aln.p, bin.d_status.p,
+                           bin.d_ids.p, n, ctx->opt.n_occ, b.d_class.p);
+        PS_HIP(hipStreamSynchronize(s));
         bin.overflow.clear();
         std::vector<int32_t> todo;
         for (int r = 0; r < n; ++r) {
-            if (so.status[r] == RS_OK) continue;
-            if (so.status[r] == RS_BAD_SCORE) throw Error("internal: score outside the bucket range");
+            if (h_status[r] == RS_OK) continue;
+            if (h_status[r] == RS_BAD_SCORE) throw Error("internal: score outside the bucket range");
             todo.push_back(r);
         }
-        for (int tier = 1; tier < 3 && !todo.empty(); ++tier) {
+        for (int tier = 1; tier < 3 && !todo.empty(); ++tier) {          // reads that need a deeper stack / longer hit list
             b.n_overflow[tier] += (int64_t)todo.size();
             const int m = (int)todo.size();
             std::vector<uint32_t> hb((size_t)bin.n_bw * m), hm((size_t)bin.n_mw * m);
@@ -273,46 +414,99 @@ void batch_search(Batch &b)
                 for (int wv = 0; wv < bin.n_mw; ++wv) hm[(size_t)wv * m + q] = bin.h_nmask[(size_t)wv * n + todo[q]];
             }
             DevBuf<uint32_t> db, dm; db.alloc(hb.size()); dm.alloc(hm.size());
-            db.upload(hb.data(), hb.size(), ctx->stream); dm.upload(hm.data(), hm.size(), ctx->stream);
-            PinBuf t_n, t_s, t_o, t_a;
-            SearchOut s2{&t_n, &t_s, &t_o, &t_a, nullptr, nullptr, nullptr, nullptr};
-            run_search(b, bin.md, m, db.p, dm.p, ctx->pool_cap[tier], ctx->aln_cap[tier], s2);
+            db.upload(hb.data(), hb.size(), s); dm.upload(hm.data(), hm.size(), s);
+            DevBuf<AlnRec> ta; DevBuf<int32_t> tn; DevBuf<uint8_t> ts;
+            ta.alloc((size_t)m * ctx->aln_cap[tier]); tn.alloc(m); ts.alloc(m);
+            run_search(b, bin.md, m, db.p, dm.p, ctx->pool_cap[tier], ctx->aln_cap[tier], ta.p, tn.p, ts.p);
+            std::vector<uint8_t> st(m); ts.download(st.data(), m, s);
+            std::vector<int32_t> na; std::vector<uint32_t> off; std::vector<AlnRec> al;
+            download_alns(ctx, m, ctx->aln_cap[tier], ta.p, tn.p, na, off, al);
             std::vector<int32_t> still;
             for (int q = 0; q < m; ++q) {
-                if (s2.status[q] == RS_BAD_SCORE) throw Error("internal: score outside the bucket range");
-                if (s2.status[q] != RS_OK) { still.push_back(todo[q]); continue; }
-                bin.h_n_aln[todo[q]] = s2.n_aln[q];
-                bin.overflow[todo[q]] = std::vector<AlnRec>(s2.alns + s2.off[q], s2.alns + s2.off[q + 1]);
+                if (st[q] == RS_BAD_SCORE) throw Error("internal: score outside the bucket range");
+                if (st[q] != RS_OK) { still.push_back(todo[q]); continue; }
+                bin.overflow[todo[q]] = std::vector<AlnRec>(al.begin() + off[q], al.begin() + off[q + 1]);
             }
             todo.swap(still);
         }
         if (!todo.empty()) throw Error("a read exceeded the largest search tier (stack or hit capacity)");
     }
     KStats hs[3];
-    b.d_stats.download(hs, 3, ctx->stream);
-    PS_HIP(hipStreamSynchronize(ctx->stream));
-    b.st_width = hs[0]; b.st_backtrack = hs[1];
-    // classify reads for the tie-break stream: a read whose best score is reached by exactly one SA
-    // interval always consumes two draws; the others ("hard") are data dependent
+    b.d_stats.download(hs, 3, s);
+    // classes to the host; the host-finished subset and its position in the tie-break stream
     auto tcl = Clock::now();
-    const int64_t N = b.rs.n;
-    b.n_best.assign((size_t)N, 0); b.hard.clear(); b.easy_before.clear(); b.n_easy = 0;
-    for (int64_t g = 0; g < N; ++g) {
-        int na; const AlnRec *al = b.alns_of(g, na);
-        int nb = 0;
-        for (; nb < na && al[nb].score == al[0].score; ++nb) {}
-        b.n_best[g] = (uint8_t)(nb > 255 ? 255 : nb);
-        if (nb == 1) ++b.n_easy;
-        else if (nb >= 2) { b.hard.push_back(g); b.easy_before.push_back(b.n_easy); }
+    b.h_class = (uint8_t *)b.p_class.get((size_t)N + 64);
+    PS_HIP(hipMemcpyAsync(b.h_class, b.d_class.p, (size_t)N, hipMemcpyDeviceToHost, s));
+    PS_HIP(hipStreamSynchronize(s));
+    b.st_width = hs[0]; b.st_backtrack = hs[1];
+    bool patched = false;
+    for (Bin &bin : b.bins)
+        for (auto &kv : bin.overflow) {                       // larger-tier reads: class from their host-side hit list
+            const std::vector<AlnRec> &al = kv.second;
+            int nb = 0;
+            for (; nb < (int)al.size() && al[nb].score == al[0].score; ++nb) {}
+            b.h_class[bin.ids[kv.first]] = (uint8_t)((al.empty() ? 0 : (nb == 1 ? 1 : 2)) | PS_CLS_HOST);
+            patched = true;
+        }
+    if (patched) PS_HIP(hipMemcpyAsync(b.d_class.p, b.h_class, (size_t)N, hipMemcpyHostToDevice, s));
+    b.sub.clear(); b.n_class1 = 0; b.n_hard = 0;
+    {
+        int64_t e = 0, h = 0;
+        std::vector<std::vector<int32_t>> want(b.bins.size());
+        for (int64_t g = 0; g < N; ++g) {
+            const uint8_t c = b.h_class[g];
+            if (c & PS_CLS_HOST) {
+                SubRead sr; sr.g = g; sr.cls = c & 3; sr.easy_before = e; sr.hard_before = h;
+                b.sub.push_back(std::move(sr));
+                const Bin &bin = b.bins[b.read_bin[g]];
+                if (bin.overflow.empty() || !bin.overflow.count(b.read_local[g])) want[b.read_bin[g]].push_back(b.read_local[g]);
+            }
+            e += (c & 3) == 1; h += (c & 3) == 2;
+        }
+        b.n_class1 = e; b.n_hard = h;
+        // hit lists of the subset: gathered on the device, one small download per bin
+        std::vector<size_t> cursor(b.bins.size(), 0);
+        std::vector<std::vector<AlnRec>> got(b.bins.size()); std::vector<std::vector<int32_t>> got_n(b.bins.size());
+        for (size_t bi = 0; bi < b.bins.size(); ++bi) {
+            const int m = (int)want[bi].size();
+            if (!m) continue;
+            Bin &bin = b.bins[bi];
+            int32_t *d_loc = ctx->ws_get<int32_t>("sub_local", m); AlnRec *d_out = ctx->ws_get<AlnRec>("sub_alns", (size_t)m * bin.aln_cap);
+            int32_t *d_no = ctx->ws_get<int32_t>("sub_n", m);
+            PS_HIP(hipMemcpyAsync(d_loc, want[bi].data(), (size_t)m * 4, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(k_gather_sub, dim3((m + 255) / 256), dim3(256), 0, s, bin.d_alns.p, bin.aln_cap, bin.d_n_aln.p, d_loc, m, d_out, d_no);
+            got[bi].resize((size_t)m * bin.aln_cap); got_n[bi].resize(m);
+            PS_HIP(hipMemcpyAsync(got[bi].data(), d_out, got[bi].size() * sizeof(AlnRec), hipMemcpyDeviceToHost, s));
+            PS_HIP(hipMemcpyAsync(got_n[bi].data(), d_no, (size_t)m * 4, hipMemcpyDeviceToHost, s));
+            PS_HIP(hipStreamSynchronize(s));
+        }
+        for (SubRead &sr : b.sub) {
+            const int bi = b.read_bin[sr.g]; Bin &bin = b.bins[bi];
+            auto it = bin.overflow.empty() ? bin.overflow.end() : bin.overflow.find(b.read_local[sr.g]);
+            if (it != bin.overflow.end()) sr.alns = it->second;
+            else {
+                const size_t q = cursor[bi]++;
+                sr.alns.assign(got[bi].begin() + q * bin.aln_cap, got[bi].begin() + q * bin.aln_cap + got_n[bi][q]);
+            }
+        }
     }
-    b.hits.resize((size_t)N);        // every record is rewritten by the selection stage
     b.tm.ms_classify = ms_since(tcl);
     b.searched = true; b.selected_hard = b.selected = b.located = false;
     b.tm.ms_total = ms_since(t0);
 }
 
-const AlnRec *Batch::alns_of(int64_t g, int &n) const
+void Batch::ensure_host_alns()
 {
+    for (Bin &bin : bins) {
+        if (bin.host_alns_valid) continue;
+        download_alns(ctx, (int)bin.ids.size(), bin.aln_cap, bin.d_alns.p, bin.d_n_aln.p, bin.h_n_aln, bin.h_off, bin.h_alns);
+        for (auto &kv : bin.overflow) bin.h_n_aln[kv.first] = (int32_t)kv.second.size();
+        bin.host_alns_valid = true;
+    }
+}
+const AlnRec *Batch::alns_of(int64_t g, int &n)
+{
+    ensure_host_alns();
     const Bin &bin = bins[read_bin[g]];
     int32_t r = read_local[g];
     n = bin.h_n_aln[r];
@@ -320,7 +514,7 @@ const AlnRec *Batch::alns_of(int64_t g, int &n) const
         auto it = bin.overflow.find(r);
         if (it != bin.overflow.end()) return it->second.data();
     }
-    return bin.h_alns + bin.h_off[r];
+    return bin.h_alns.data() + bin.h_off[r];
 }
 
 // ----------------------------------------------------- tie-break selection -----
@@ -350,26 +544,25 @@ static int choose_main(const AlnRec *al, int na, Rng48 &rng, Hit &h)
     return draws;
 }
 
+// the sequential part of the stream: reads with several best-score intervals, in input order
 void batch_select_hard(Batch &b, uint64_t draws_before, uint64_t *draws_after)
 {
     if (!b.searched) throw Error("select before search");
     auto t0 = Clock::now();
     b.draws_in = draws_before;
-    b.hard_draws_cum.assign(b.hard.size(), 0);
+    b.hard_draws_cum.assign((size_t)b.n_hard, 0);
     Rng48 rng(11);
     rng.jump(draws_before);
     uint64_t H = 0; int64_t e_prev = 0;
-    for (size_t q = 0; q < b.hard.size(); ++q) {
-        const int64_t g = b.hard[q];
-        rng.jump(2ull * (uint64_t)(b.easy_before[q] - e_prev));   // the single-best reads in between took two draws each
-        e_prev = b.easy_before[q];
-        int na; const AlnRec *al = b.alns_of(g, na);
-        Hit &h = b.hits[g];
-        h = Hit();
-        H += (uint64_t)choose_main(al, na, rng, h);
-        b.hard_draws_cum[q] = H;
+    for (SubRead &sr : b.sub) {
+        if (sr.cls != 2) continue;
+        rng.jump(2ull * (uint64_t)(sr.easy_before - e_prev));      // the single-best reads in between took two draws each
+        e_prev = sr.easy_before;
+        sr.hit = Hit();
+        H += (uint64_t)choose_main(sr.alns.data(), (int)sr.alns.size(), rng, sr.hit);
+        b.hard_draws_cum[(size_t)sr.hard_before] = H;
     }
-    b.draws_out = draws_before + 2ull * (uint64_t)b.n_easy + H;
+    b.draws_out = draws_before + 2ull * (uint64_t)b.n_class1 + H;
     if (draws_after) *draws_after = b.draws_out;
     b.selected_hard = true;
     b.tm.ms_select += ms_since(t0); b.tm.ms_sel_hard = ms_since(t0);
@@ -378,67 +571,65 @@ void batch_select_hard(Batch &b, uint64_t draws_before, uint64_t *draws_after)
 void batch_select_easy(Batch &b, int threads)
 {
     if (!b.selected_hard) throw Error("select_easy before select_hard");
+    Ctx *ctx = b.ctx; hipStream_t s = ctx->stream;
     auto t0 = Clock::now();
     const int64_t N = b.rs.n;
-    if (threads < 1) threads = 1;
-    if (threads > 64) threads = 64;
-    const int n_occ = b.ctx->opt.n_occ;
-    std::vector<std::vector<Multi>> mul_chunks((size_t)threads);
-    std::vector<std::string> errs((size_t)threads);
-    auto work = [&](int t) {
-        const int64_t g0 = N * t / threads, g1 = N * (t + 1) / threads;
-        // stream position at g0: single-best reads before it and hard reads before it
-        size_t q = std::lower_bound(b.hard.begin(), b.hard.end(), g0) - b.hard.begin();
-        int64_t easy = 0;
-        for (int64_t g = 0; g < g0; ++g) easy += b.n_best[g] == 1;   // prefix count (cheap byte scan)
-        Rng48 rng(11);
-        rng.jump(b.draws_in + 2ull * (uint64_t)easy + (q ? b.hard_draws_cum[q - 1] : 0ull));
-        std::vector<Multi> &mul = mul_chunks[t];
-        for (int64_t g = g0; g < g1; ++g) {
-            Hit &h = b.hits[g];
-            int na; const AlnRec *al = b.alns_of(g, na);
-            if (b.n_best[g] == 0) { h = Hit(); h.type = 0; h.pos = -1; h.multi_begin = (int32_t)mul.size(); continue; }
-            if (b.n_best[g] == 1) {
-                h = Hit();
-                Rng48 probe = rng;
-                if (probe.step() == 0) { errs[t] = "tie-break stream hit the zero state; sequential replay required"; return; }
-                choose_main(al, na, rng, h);
-            } else {
-                const uint64_t prev = q ? b.hard_draws_cum[q - 1] : 0ull;
-                const uint64_t used = b.hard_draws_cum[q] - prev;
-                for (uint64_t d = 0; d < used; ++d) rng.step();   // selection already done in select_hard
-                ++q;
-            }
-            h.pos = -1; h.multi_begin = (int32_t)mul.size(); h.n_multi = 0;
-            // alternative hits (samse -n): listed only if all occurrences of all hits number <= n_occ+1
-            if (n_occ > 0) {
-                int tot = 0;
-                for (int k = 0; k < na; ++k) tot += (int)((uint64_t)(al[k].l - al[k].k) + 1ull);
-                if (tot >= 0 && tot <= n_occ + 1) {
-                    for (int k = 0; k < na; ++k)
-                        for (uint64_t row = al[k].k; row <= al[k].l; ++row) {
-                            Multi m; std::memset(&m, 0, sizeof m);
-                            m.row = (bwtint)row; m.gap = al[k].n_gapo + al[k].n_gape; m.mm = al[k].n_mm;
-                            m.ref_shift = (int)al[k].n_del - (int)al[k].n_ins; m.pos = -1;
-                            mul.push_back(m); ++h.n_multi;
-                        }
-                }
-            }
-        }
-    };
-    std::vector<std::thread> th;
-    for (int t = 1; t < threads; ++t) th.emplace_back(work, t);
-    work(0);
-    for (auto &x : th) x.join();
-    for (auto &e : errs) if (!e.empty()) throw Error(e);
-    // stitch the per-thread alternative-hit lists
-    b.multis.clear();
-    for (int t = 0; t < threads; ++t) {
-        const int64_t g0 = N * t / threads, g1 = N * (t + 1) / threads;
-        const int32_t base = (int32_t)b.multis.size();
-        if (base) for (int64_t g = g0; g < g1; ++g) b.hits[g].multi_begin += base;
-        b.multis.insert(b.multis.end(), mul_chunks[t].begin(), mul_chunks[t].end());
+    (void)threads;
+    // ---- device: prefix counts of the two draw classes, then every single-best read picks its occurrence ----
+    if (b.d_sel.n < (size_t)N) { b.d_sel.alloc((size_t)N); b.d_fin.alloc((size_t)N); b.d_rows.alloc((size_t)N + 1); b.d_pos.alloc((size_t)N + 1); b.d_eb.alloc((size_t)N); b.d_hb.alloc((size_t)N); }
+    {
+        uint32_t *f1 = ctx->ws_get<uint32_t>("flag1", (size_t)N), *f2 = ctx->ws_get<uint32_t>("flag2", (size_t)N);
+        hipLaunchKernelGGL(k_class_flags, dim3(2048), dim3(256), 0, s, b.d_class.p, (long long)N, f1, f2);
+        size_t tb = 0;
+        PS_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, f1, b.d_eb.p, (size_t)N, s));
+        uint8_t *tmp = ctx->ws_get<uint8_t>("scan_tmp", tb ? tb : 1);
+        PS_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tb, f1, b.d_eb.p, (size_t)N, s));
+        PS_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tb, f2, b.d_hb.p, (size_t)N, s));
     }
+    unsigned long long *d_cum = ctx->ws_get<unsigned long long>("hard_cum", (size_t)b.n_hard + 1);
+    if (b.n_hard) PS_HIP(hipMemcpyAsync(d_cum, b.hard_draws_cum.data(), (size_t)b.n_hard * 8, hipMemcpyHostToDevice, s));
+    int *d_err = ctx->ws_get<int>("sel_err", 4);
+    PS_HIP(hipMemsetAsync(d_err, 0, 16, s));
+    for (Bin &bin : b.bins) {
+        SelectArgs a;
+        a.alns = bin.d_alns.p; a.aln_cap = bin.aln_cap; a.n_aln = bin.d_n_aln.p; a.ids = bin.d_ids.p; a.n = (int)bin.ids.size();
+        a.cls = b.d_class.p; a.e_before = b.d_eb.p; a.h_before = b.d_hb.p; a.hard_cum = d_cum; a.draws_in = b.draws_in;
+        a.sel = b.d_sel.p; a.rows = b.d_rows.p; a.err = d_err;
+        hipLaunchKernelGGL(k_select, dim3(std::min((a.n + 255) / 256, 4096)), dim3(256), 0, s, a);
+    }
+    // ---- host: the subset (its class-1 members by the same offset algebra, then the alternative-hit lists) ----
+    const int n_occ = ctx->opt.n_occ;
+    b.multis.clear();
+    for (SubRead &sr : b.sub) {
+        const int na = (int)sr.alns.size();
+        Hit &h = sr.hit;
+        if (sr.cls == 0 || na == 0) { h = Hit(); h.type = 0; h.pos = -1; continue; }
+        if (sr.cls == 1) {
+            h = Hit();
+            Rng48 rng(11);
+            rng.jump(b.draws_in + 2ull * (uint64_t)sr.easy_before + (sr.hard_before ? b.hard_draws_cum[(size_t)sr.hard_before - 1] : 0ull));
+            Rng48 probe = rng;
+            if (probe.step() == 0) throw Error("tie-break stream hit the zero state; sequential replay required");
+            choose_main(sr.alns.data(), na, rng, h);
+        }
+        h.pos = -1; h.multi_begin = (int32_t)b.multis.size(); h.n_multi = 0;
+        if (n_occ > 0) {                     // alternative hits (samse -n): only if all occurrences of all hits number <= n_occ+1
+            int tot = 0;
+            for (int k = 0; k < na; ++k) tot += (int)((uint64_t)(sr.alns[k].l - sr.alns[k].k) + 1ull);
+            if (tot >= 0 && tot <= n_occ + 1)
+                for (int k = 0; k < na; ++k)
+                    for (uint64_t row = sr.alns[k].k; row <= sr.alns[k].l; ++row) {
+                        Multi m; std::memset(&m, 0, sizeof m);
+                        m.row = (bwtint)row; m.gap = sr.alns[k].n_gapo + sr.alns[k].n_gape; m.mm = sr.alns[k].n_mm;
+                        m.ref_shift = (int)sr.alns[k].n_del - (int)sr.alns[k].n_ins; m.pos = -1;
+                        b.multis.push_back(m); ++h.n_multi;
+                    }
+        }
+    }
+    int err = 0;
+    PS_HIP(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, s));
+    PS_HIP(hipStreamSynchronize(s));
+    if (err) throw Error("tie-break stream hit the zero state; sequential replay required");
     b.selected = true;
     b.tm.ms_select += ms_since(t0); b.tm.ms_sel_easy = ms_since(t0);
 }
@@ -481,6 +672,25 @@ static int fix_cigar(uint32_t *cigar, int n, int64_t &rb)
     return n;
 }
 
+// banded DP kernel over a list of items of one length bin; cigars come back to the host
+static void run_refine(Batch &b, Bin &bin, const RefineItem *d_items, int n_it, std::vector<uint32_t> &cig, std::vector<int32_t> &nc)
+{
+    Ctx *ctx = b.ctx; hipStream_t s = ctx->stream;
+    uint32_t *d_cig = ctx->ws_get<uint32_t>("rf_cig", (size_t)n_it * PS_MAX_CIGAR); int32_t *d_nc = ctx->ws_get<int32_t>("rf_nc", n_it);
+    int blocks = (n_it + 63) / 64; if (blocks > 2048) blocks = 2048;
+    const int tmax = bin.len + 64;
+    RefineArgs ra;
+    ra.ix = ctx->ix.view; ra.n_items = n_it; ra.len = bin.len; ra.n_reads = (int)bin.ids.size();
+    ra.bases = bin.bases.p; ra.nmask = bin.nmask.p; ra.items = d_items; ra.cigar = d_cig; ra.n_cigar = d_nc;
+    ra.z_per_block = (size_t)64 * tmax * (bin.len < 2 * tmax + 1 ? bin.len : 2 * tmax + 1);
+    ra.zbuf = ctx->ws_get<uint8_t>("rf_z", ra.z_per_block * blocks);
+    { EvTimer t(s); launch_refine(ra, blocks, s); PS_HIP(hipGetLastError()); b.tm.ms_refine += t.stop(); }
+    cig.resize((size_t)n_it * PS_MAX_CIGAR); nc.resize(n_it);
+    PS_HIP(hipMemcpyAsync(cig.data(), d_cig, cig.size() * 4, hipMemcpyDeviceToHost, s));
+    PS_HIP(hipMemcpyAsync(nc.data(), d_nc, (size_t)n_it * 4, hipMemcpyDeviceToHost, s));
+    PS_HIP(hipStreamSynchronize(s));
+}
+
 void batch_locate(Batch &b)
 {
     if (!b.selected) throw Error("locate before select");
@@ -488,127 +698,153 @@ void batch_locate(Batch &b)
     require_device(ctx->device);
     const int64_t N = b.rs.n, l_pac = ctx->ix.ref.l_pac;
     auto t0 = Clock::now();
-    // rows to locate: one slot per read (row 0 = nothing to walk for unmapped reads), then the alternatives
-    const size_t n_rows = (size_t)N + b.multis.size(), multi_base = (size_t)N;
-    bwtint *p_rows = ctx->pin_get<bwtint>("rows", n_rows + 1);
-    {
-        int nt = std::max(1, std::min(ctx->host_threads, 64));
-        auto fill = [&](int t) {
-            for (int64_t g = N * t / nt; g < N * (t + 1) / nt; ++g) p_rows[g] = b.hits[g].type != 0 ? b.hits[g].sa : 0;
-            const int64_t M = (int64_t)b.multis.size();
-            for (int64_t j = M * t / nt; j < M * (t + 1) / nt; ++j) p_rows[multi_base + j] = b.multis[j].row;
-        };
-        std::vector<std::thread> th;
-        for (int t = 1; t < nt; ++t) th.emplace_back(fill, t);
-        fill(0);
-        for (auto &x : th) x.join();
+    // ---- device-finished reads: SA walk, strand / MAPQ, queue of gapped hits ----
+    { EvTimer t(s); launch_sa2pos(ctx->ix.view, b.d_rows.p, b.d_pos.p, (int)N, b.d_stats.p + 2, s); PS_HIP(hipGetLastError()); b.tm.ms_sa2pos += t.stop(); }
+    uint8_t logn[256]; logn[0] = 0;
+    for (int n = 1; n < 256; ++n) logn[n] = (uint8_t)mapq_logn(n);
+    uint8_t *d_logn = ctx->ws_get<uint8_t>("logn", 256);
+    PS_HIP(hipMemcpyAsync(d_logn, logn, 256, hipMemcpyHostToDevice, s));
+    b.dev_cigars.clear();
+    struct BinItems { RefineItem *d_items; int32_t *d_item_g; unsigned int *d_n; unsigned int n; };
+    std::vector<BinItems> bi_items(b.bins.size());
+    for (size_t bi = 0; bi < b.bins.size(); ++bi) {
+        Bin &bin = b.bins[bi];
+        const int n = (int)bin.ids.size();
+        BinItems &it = bi_items[bi];
+        it.d_items = ctx->ws_get<RefineItem>("post_items" + std::to_string(bi), n); it.d_item_g = ctx->ws_get<int32_t>("post_item_g" + std::to_string(bi), n);
+        it.d_n = ctx->ws_get<unsigned int>("post_n" + std::to_string(bi), 4);
+        PS_HIP(hipMemsetAsync(it.d_n, 0, 16, s));
+        PostArgs a;
+        a.ids = bin.d_ids.p; a.n = n; a.len = bin.len; a.l_pac = l_pac; a.cls = b.d_class.p; a.sel = b.d_sel.p; a.pos = b.d_pos.p; a.fin = b.d_fin.p;
+        a.budget = budget_diffs(ctx->opt, bin.len); a.profile = ctx->opt.profile; a.unit = ctx->opt.unit; a.logn = d_logn;
+        a.items = it.d_items; a.item_g = it.d_item_g; a.n_items = it.d_n;
+        hipLaunchKernelGGL(k_post, dim3(std::min((n + 255) / 256, 4096)), dim3(256), 0, s, a);
+        PS_HIP(hipMemcpyAsync(&it.n, it.d_n, 4, hipMemcpyDeviceToHost, s));
     }
-    b.tm.ms_rows = ms_since(t0);
-    bwtint *pos = ctx->pin_get<bwtint>("pos", n_rows + 1);
-    if (n_rows) {
-        bwtint *d_rows = ctx->ws_get<bwtint>("rows", n_rows), *d_pos = ctx->ws_get<bwtint>("pos", n_rows);
-        PS_HIP(hipMemcpyAsync(d_rows, p_rows, n_rows * sizeof(bwtint), hipMemcpyHostToDevice, s));
-        { EvTimer t(s); launch_sa2pos(ctx->ix.view, d_rows, d_pos, (int)n_rows, b.d_stats.p + 2, s); PS_HIP(hipGetLastError()); b.tm.ms_sa2pos += t.stop(); }
-        PS_HIP(hipMemcpyAsync(pos, d_pos, n_rows * sizeof(bwtint), hipMemcpyDeviceToHost, s));
-        PS_HIP(hipStreamSynchronize(s));
-        PS_HIP(hipMemcpy(&b.st_sa2pos, b.d_stats.p + 2, sizeof(KStats), hipMemcpyDeviceToHost));
-    }
-    auto t1 = Clock::now();
-    std::vector<std::vector<RefineItem>> items(b.bins.size());
-    struct Back { int64_t g; int32_t multi; };             // multi < 0: main hit
-    std::vector<std::vector<Back>> back(b.bins.size());
-    {   // strand / MAPQ / alternative-hit filter: independent per read
-        int nt = std::max(1, std::min(ctx->host_threads, 64));
-        auto work = [&](int t) {
-            for (int64_t g = N * t / nt; g < N * (t + 1) / nt; ++g) {
-                Hit &h = b.hits[g];
-                const int len = b.rs.len[g];
-                if (h.type != 0) {
-                    int strand = 0;
-                    h.pos = to_forward(pos[g], l_pac, len + h.ref_shift, strand);
-                    h.strand = strand;
-                    h.mapq = approx_mapq(h, ctx->opt, len);
-                    if (h.pos < 0) h.type = 0;
-                }
-                int kept = 0;
-                for (int j = 0; j < h.n_multi; ++j) {
-                    Multi &m = b.multis[h.multi_begin + j];
-                    int strand = 0;
-                    m.pos = to_forward(pos[multi_base + h.multi_begin + j], l_pac, len + m.ref_shift, strand);
-                    m.strand = strand;
-                    if (m.pos != h.pos && m.pos >= 0) b.multis[h.multi_begin + kept++] = m;
-                }
-                h.n_multi = kept;
-            }
-        };
-        std::vector<std::thread> th;
-        for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
-        work(0);
-        for (auto &x : th) x.join();
-    }
-    for (int64_t g = 0; g < N; ++g) {                       // gapped hits go to the banded-DP kernel
-        Hit &h = b.hits[g];
-        if (h.n_multi == 0 && !(h.type != 0 && h.n_gapo)) continue;
-        const int bi = b.read_bin[g];
-        for (int j = 0; j < h.n_multi; ++j) {
-            Multi &m = b.multis[h.multi_begin + j];
-            if (m.gap) { items[bi].push_back(RefineItem{b.read_local[g], (bwtint)m.pos, m.ref_shift, m.strand}); back[bi].push_back(Back{g, j}); }
+    b.h_sel = (SelRec *)b.p_sel.get((size_t)N * sizeof(SelRec) + 64);
+    b.h_fin = (FinRec *)b.p_fin.get((size_t)N * sizeof(FinRec) + 64);
+    PS_HIP(hipMemcpyAsync(b.h_sel, b.d_sel.p, (size_t)N * sizeof(SelRec), hipMemcpyDeviceToHost, s));
+    PS_HIP(hipMemcpyAsync(b.h_fin, b.d_fin.p, (size_t)N * sizeof(FinRec), hipMemcpyDeviceToHost, s));
+    PS_HIP(hipStreamSynchronize(s));
+    PS_HIP(hipMemcpy(&b.st_sa2pos, b.d_stats.p + 2, sizeof(KStats), hipMemcpyDeviceToHost));
+    for (size_t bi = 0; bi < b.bins.size(); ++bi) {            // gapped device-finished hits: banded DP, CIGAR clean-up
+        BinItems &it = bi_items[bi];
+        if (!it.n) continue;
+        std::vector<uint32_t> cig; std::vector<int32_t> nc; std::vector<int32_t> gs(it.n);
+        run_refine(b, b.bins[bi], it.d_items, (int)it.n, cig, nc);
+        PS_HIP(hipMemcpy(gs.data(), it.d_item_g, (size_t)it.n * 4, hipMemcpyDeviceToHost));
+        for (unsigned int q = 0; q < it.n; ++q) {
+            const int64_t g = gs[q];
+            uint32_t *c = cig.data() + (size_t)q * PS_MAX_CIGAR;
+            int64_t rb = b.h_fin[g].pos;
+            const int n_c = fix_cigar(c, nc[q], rb);
+            if (n_c > PS_HIT_CIGAR) throw Error("CIGAR with more than 8 operations (raise PS_HIT_CIGAR for max_gapo > 2)");
+            DevCigar dc; dc.g = g; dc.n = n_c; std::memcpy(dc.c, c, sizeof dc.c);
+            b.dev_cigars.push_back(dc);
+            b.h_fin[g].pos = rb;
+            if (n_c == 0) b.h_fin[g].type = 0;
         }
-        if (h.type != 0 && h.n_gapo) { items[bi].push_back(RefineItem{b.read_local[g], (bwtint)h.pos, h.ref_shift, h.strand}); back[bi].push_back(Back{g, -1}); }
+    }
+    std::sort(b.dev_cigars.begin(), b.dev_cigars.end(), [](const DevCigar &x, const DevCigar &y) { return x.g < y.g; });
+    auto t1 = Clock::now();
+    // ---- host-finished subset: its rows (main + alternatives) through the same SA kernel, then strand / MAPQ / DP ----
+    const size_t M = b.sub.size(), n_rows = M + b.multis.size();
+    if (n_rows) {
+        std::vector<bwtint> rows(n_rows), pos(n_rows);
+        for (size_t q = 0; q < M; ++q) rows[q] = b.sub[q].hit.type != 0 ? b.sub[q].hit.sa : 0;
+        for (size_t j = 0; j < b.multis.size(); ++j) rows[M + j] = b.multis[j].row;
+        bwtint *d_r = ctx->ws_get<bwtint>("sub_rows", n_rows), *d_p = ctx->ws_get<bwtint>("sub_pos", n_rows);
+        PS_HIP(hipMemcpyAsync(d_r, rows.data(), n_rows * sizeof(bwtint), hipMemcpyHostToDevice, s));
+        { EvTimer t(s); launch_sa2pos(ctx->ix.view, d_r, d_p, (int)n_rows, nullptr, s); PS_HIP(hipGetLastError()); b.tm.ms_sa2pos += t.stop(); }
+        PS_HIP(hipMemcpyAsync(pos.data(), d_p, n_rows * sizeof(bwtint), hipMemcpyDeviceToHost, s));
+        PS_HIP(hipStreamSynchronize(s));
+        std::vector<std::vector<RefineItem>> items(b.bins.size());
+        struct Back { size_t q; int32_t multi; };             // multi < 0: main hit
+        std::vector<std::vector<Back>> back(b.bins.size());
+        for (size_t q = 0; q < M; ++q) {
+            SubRead &sr = b.sub[q]; Hit &h = sr.hit;
+            const int len = b.rs.len[sr.g], bi = b.read_bin[sr.g];
+            if (h.type != 0) {
+                int strand = 0;
+                h.pos = to_forward(pos[q], l_pac, len + h.ref_shift, strand);
+                h.strand = strand;
+                h.mapq = approx_mapq(h, ctx->opt, len);
+                if (h.pos < 0) h.type = 0;
+            }
+            int kept = 0;
+            for (int j = 0; j < h.n_multi; ++j) {
+                Multi &m = b.multis[h.multi_begin + j];
+                int strand = 0;
+                m.pos = to_forward(pos[M + h.multi_begin + j], l_pac, len + m.ref_shift, strand);
+                m.strand = strand;
+                if (m.pos != h.pos && m.pos >= 0) b.multis[h.multi_begin + kept++] = m;
+            }
+            h.n_multi = kept;
+            for (int j = 0; j < h.n_multi; ++j) {
+                Multi &m = b.multis[h.multi_begin + j];
+                if (m.gap) { items[bi].push_back(RefineItem{b.read_local[sr.g], (bwtint)m.pos, m.ref_shift, m.strand}); back[bi].push_back(Back{q, j}); }
+            }
+            if (h.type != 0 && h.n_gapo) { items[bi].push_back(RefineItem{b.read_local[sr.g], (bwtint)h.pos, h.ref_shift, h.strand}); back[bi].push_back(Back{q, -1}); }
+        }
+        for (size_t bi = 0; bi < b.bins.size(); ++bi) {
+            const int n_it = (int)items[bi].size();
+            if (!n_it) continue;
+            RefineItem *d_it = ctx->ws_get<RefineItem>("sub_items", n_it);
+            PS_HIP(hipMemcpyAsync(d_it, items[bi].data(), (size_t)n_it * sizeof(RefineItem), hipMemcpyHostToDevice, s));
+            std::vector<uint32_t> cig; std::vector<int32_t> nc;
+            run_refine(b, b.bins[bi], d_it, n_it, cig, nc);
+            for (int q = 0; q < n_it; ++q) {
+                const Back &bk = back[bi][q];
+                Hit &h = b.sub[bk.q].hit;
+                uint32_t *c = cig.data() + (size_t)q * PS_MAX_CIGAR;
+                if (bk.multi < 0) {
+                    int64_t rb = h.pos;
+                    h.n_cigar = fix_cigar(c, nc[q], rb);
+                    if (h.n_cigar > PS_HIT_CIGAR) throw Error("CIGAR with more than 8 operations (raise PS_HIT_CIGAR for max_gapo > 2)");
+                    std::memcpy(h.cigar, c, sizeof h.cigar);
+                    h.pos = rb;
+                    if (h.n_cigar == 0) h.type = 0;
+                } else {
+                    Multi &m = b.multis[h.multi_begin + bk.multi];
+                    int64_t rb = m.pos;
+                    m.n_cigar = fix_cigar(c, nc[q], rb);
+                    std::memcpy(m.cigar, c, sizeof m.cigar);
+                    m.pos = rb;
+                }
+            }
+        }
+        for (SubRead &sr : b.sub) {          // alternatives whose gapped refinement produced nothing are dropped
+            Hit &h = sr.hit;
+            int kept = 0;
+            for (int j = 0; j < h.n_multi; ++j) {
+                Multi &m = b.multis[h.multi_begin + j];
+                if (m.gap && m.n_cigar == 0) continue;
+                b.multis[h.multi_begin + kept++] = m;
+            }
+            h.n_multi = kept;
+        }
     }
     b.tm.ms_host_post += ms_since(t1);
-    // banded DP kernel, one launch per length bin
-    for (size_t bi = 0; bi < b.bins.size(); ++bi) {
-        const int n_it = (int)items[bi].size();
-        if (!n_it) continue;
-        Bin &bin = b.bins[bi];
-        DevBuf<RefineItem> d_it; DevBuf<uint32_t> d_cig; DevBuf<int32_t> d_nc; DevBuf<uint8_t> zbuf;
-        d_it.alloc(n_it); d_cig.alloc((size_t)n_it * PS_MAX_CIGAR); d_nc.alloc(n_it);
-        d_it.upload(items[bi].data(), n_it, s);
-        int blocks = (n_it + 63) / 64; if (blocks > 2048) blocks = 2048;
-        const int tmax = bin.len + 64;
-        RefineArgs ra;
-        ra.ix = ctx->ix.view; ra.n_items = n_it; ra.len = bin.len; ra.n_reads = (int)bin.ids.size();
-        ra.bases = bin.bases.p; ra.nmask = bin.nmask.p; ra.items = d_it.p; ra.cigar = d_cig.p; ra.n_cigar = d_nc.p;
-        ra.z_per_block = (size_t)64 * tmax * (bin.len < 2 * tmax + 1 ? bin.len : 2 * tmax + 1);
-        zbuf.alloc(ra.z_per_block * blocks); ra.zbuf = zbuf.p;
-        { EvTimer t(s); launch_refine(ra, blocks, s); PS_HIP(hipGetLastError()); b.tm.ms_refine += t.stop(); }
-        std::vector<uint32_t> cig((size_t)n_it * PS_MAX_CIGAR); std::vector<int32_t> nc(n_it);
-        d_cig.download(cig.data(), cig.size(), s); d_nc.download(nc.data(), n_it, s);
-        PS_HIP(hipStreamSynchronize(s));
-        for (int q = 0; q < n_it; ++q) {
-            const Back &bk = back[bi][q];
-            Hit &h = b.hits[bk.g];
-            uint32_t *c = cig.data() + (size_t)q * PS_MAX_CIGAR;
-            if (bk.multi < 0) {
-                int64_t rb = h.pos;
-                h.n_cigar = fix_cigar(c, nc[q], rb);
-                if (h.n_cigar > PS_HIT_CIGAR) throw Error("CIGAR with more than 8 operations (raise PS_HIT_CIGAR for max_gapo > 2)");
-                std::memcpy(h.cigar, c, sizeof h.cigar);
-                h.pos = rb;
-                if (h.n_cigar == 0) h.type = 0;
-            } else {
-                Multi &m = b.multis[h.multi_begin + bk.multi];
-                int64_t rb = m.pos;
-                m.n_cigar = fix_cigar(c, nc[q], rb);
-                std::memcpy(m.cigar, c, sizeof m.cigar);
-                m.pos = rb;
-            }
-        }
-    }
-    // alternatives whose gapped refinement produced nothing are dropped
-    for (int64_t g = 0; g < N; ++g) {
-        Hit &h = b.hits[g];
-        int kept = 0;
-        for (int j = 0; j < h.n_multi; ++j) {
-            Multi &m = b.multis[h.multi_begin + j];
-            if (m.gap && m.n_cigar == 0) continue;
-            b.multis[h.multi_begin + kept++] = m;
-        }
-        h.n_multi = kept;
-    }
     b.located = true;
     b.tm.ms_total += ms_since(t0);
+}
+
+// one read's alignment record: from the host-finished subset, else assembled from the device records
+void Batch::hit_of(int64_t g, Hit &h) const
+{
+    if (h_class[g] & PS_CLS_HOST) {
+        auto it = std::lower_bound(sub.begin(), sub.end(), g, [](const SubRead &s, int64_t v) { return s.g < v; });
+        h = it->hit;
+        return;
+    }
+    const SelRec &s = h_sel[g]; const FinRec &f = h_fin[g];
+    h = Hit();
+    h.sa = s.sa; h.type = f.type; h.pos = f.type ? f.pos : -1; h.strand = f.strand; h.mapq = f.mapq;
+    h.n_mm = s.n_mm; h.n_gapo = s.n_gapo; h.n_gape = s.n_gape; h.ref_shift = s.ref_shift; h.score = s.score; h.c1 = s.c1; h.c2 = s.c2;
+    if (s.n_gapo && s.type) {
+        auto it = std::lower_bound(dev_cigars.begin(), dev_cigars.end(), g, [](const DevCigar &c, int64_t v) { return c.g < v; });
+        if (it != dev_cigars.end() && it->g == g) { h.n_cigar = it->n; std::memcpy(h.cigar, it->c, sizeof h.cigar); }
+    }
 }
 
 // ------------------------------------------------------------------ SAM -------
@@ -654,7 +890,7 @@ static void cal_md(const RefSeq &ref, int n_cigar, const uint32_t *cigar, int le
 static void sam_line(const Batch &b, int64_t g, std::string &o)
 {
     const ReadSet &rs = b.rs; const RefSeq &ref = b.ctx->ix.ref; const Options &opt = b.ctx->opt;
-    const Hit &h = b.hits[g];
+    Hit h; b.hit_of(g, h);
     const int len = rs.len[g];
     const uint8_t *seq = rs.seq.data() + rs.off[g];
     const char *qual = rs.has_qual ? rs.qual.data() + rs.off[g] : nullptr;
