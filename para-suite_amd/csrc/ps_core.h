@@ -203,6 +203,7 @@ PS_HD void wchain_step(const IndexView &ix, WChain &c, int base, uint32_t &w_out
 }
 
 // ----------------------------------------------------- backtracking lane ---
+static const int PS_POP_TRIES = 4;
 enum { M_FETCH = 0, M_POP = 1, M_EXACT = 2, M_EXPAND = 3, M_EXIT = 4, M_HIT = 5 };
 
 struct BtLane {
@@ -507,18 +508,24 @@ PS_HD void bt_iter(const BtArgs &a, BtLane &L, BtMem &m, int fetch_r, bool serve
         L.mode = M_POP;
     }
     if (L.mode == M_POP) {
-        int n_virtual = L.n_stack + (L.have_cur ? 1 : 0);
-        if (n_virtual == 0 || n_virtual > md.max_entries || L.status != RS_OK) { bt_finish_read(a, L); return; }
-        if (L.have_cur) L.have_cur = false;
-        else bt_pop<WIDE>(a, L, m);
-        if (L.score > L.best_score + md.s_stop) { bt_finish_read(a, L); return; }
-        int rem = L.max_units - L.units;
-        if (rem < 0) return;
-        const int mleft = (int)(((uint32_t)rem * (uint32_t)md.inv_c_min) >> 16);     // rem / c_min
-        if (L.i > 0 && mleft < (int)(m.cw[L.i - 1] & 0x7f)) return;
-        if (L.i == 0) { L.mode = M_HIT; return; }
-        if (mleft == 0 && (L.state == ST_M || md.mode_gape || L.n_gape == md.max_gape)) L.mode = M_EXACT;
-        else L.mode = M_EXPAND;
+        // A popped entry that the bounds reject right away (budget, D(i) bound) costs the lane nothing but the
+        // pop: retry within the iteration, a wasted wave iteration is far dearer than a second pop.
+#pragma unroll 1
+        for (int tries = 0; tries < PS_POP_TRIES; ++tries) {
+            int n_virtual = L.n_stack + (L.have_cur ? 1 : 0);
+            if (n_virtual == 0 || n_virtual > md.max_entries || L.status != RS_OK) { bt_finish_read(a, L); return; }
+            if (L.have_cur) L.have_cur = false;
+            else bt_pop<WIDE>(a, L, m);
+            if (L.score > L.best_score + md.s_stop) { bt_finish_read(a, L); return; }
+            const int rem = L.max_units - L.units;
+            if (rem < 0) continue;
+            const int mleft = (int)(((uint32_t)rem * (uint32_t)md.inv_c_min) >> 16);     // rem / c_min
+            if (L.i > 0 && mleft < (int)(m.cw[L.i - 1] & 0x7f)) continue;
+            if (L.i == 0) { L.mode = M_HIT; return; }
+            if (mleft == 0 && (L.state == ST_M || md.mode_gape || L.n_gape == md.max_gape)) L.mode = M_EXACT;
+            else L.mode = M_EXPAND;
+            break;
+        }
     }
     if (L.mode != M_EXACT && L.mode != M_EXPAND) return;
     // ---- the memory step, shared by both search modes: Occ(k-1,.) and Occ(l,.) -> the four child intervals ----
