@@ -203,7 +203,8 @@ PS_HD void wchain_step(const IndexView &ix, WChain &c, int base, uint32_t &w_out
 }
 
 // ----------------------------------------------------- backtracking lane ---
-static const int PS_POP_TRIES = 4;
+static const int PS_POP_TRIES = 1;   // retrying rejected pops inside one iteration was measured: the whole wave pays for the
+                                     // extra pop passes (profile mode +21 % time), so one pop per iteration
 enum { M_FETCH = 0, M_POP = 1, M_EXACT = 2, M_EXPAND = 3, M_EXIT = 4, M_HIT = 5 };
 
 struct BtLane {
