@@ -370,6 +370,59 @@ PS_HD void bt_push(const BtArgs &a, BtLane &L, BtMem &m, bool want, int i, bwtin
     }
 }
 
+// ---- lean pushes of the narrow stack (the hot path).  The caller has checked once per expansion that nine
+// free slots remain and make_model() guarantees score < 64 buckets for this variant, so a push is: read the
+// bucket head (LDS), one 16-byte store, write the head, three register updates.
+PS_HD uint32_t e16_a(int i, bool is_diff, int n_mm, int state, int n_gapo, int n_gape)
+{
+    return (uint32_t)i | ((uint32_t)(is_diff ? i : 0) << 8) | ((uint32_t)n_mm << 16) |
+           (((uint32_t)state | ((uint32_t)n_gapo << 2) | ((uint32_t)n_gape << 5)) << 24);
+}
+PS_HD uint32_t e16_b(int n_ins, int n_del, int score) { return (uint32_t)n_ins | ((uint32_t)n_del << 4) | ((uint32_t)score << 8); }
+PS_HD uint32_t slot16(BtLane &L, bool go)          // slot for one entry: the one popped last first, then fresh ones
+{
+    const bool reuse = L.free_head != PS_NIL;
+    const uint32_t idx = reuse ? L.free_head : L.bump;
+    L.bump += (go && !reuse) ? 1u : 0u;
+    L.free_head = go ? PS_NIL : L.free_head;
+    return idx;
+}
+PS_HD void push16(BtLane &L, BtMem &m, bool go, bwtint k, bwtint l, uint32_t wa, uint32_t wb, int score)
+{
+    const unsigned long long bit = 1ull << score;
+    const uint32_t idx = slot16(L, go);
+    if (go) {
+        const uint32_t next = (L.bm0 & bit) ? (uint32_t)m.heads16[score] : PS_NIL16;
+        Entry16 e; e.k = k; e.l = l; e.a = wa; e.b = wb | (next << 16);
+        store16(reinterpret_cast<Entry16 *>(m.pool) + idx, e);
+        m.heads16[score] = (uint16_t)idx;
+    }
+    L.bm0 |= go ? bit : 0ull;
+    L.n_stack += go ? 1 : 0; L.st.pushes += go ? 1u : 0u;
+}
+// up to four children that differ only in their interval (the deletion children): one head read, one head write
+PS_HD void push16_group(BtLane &L, BtMem &m, bool go_all, const bwtint nk[4], const bwtint nl[4], uint32_t wa, uint32_t wb, int score)
+{
+    const unsigned long long bit = 1ull << score;
+    bool any = false;
+    uint32_t next = PS_NIL16;
+    if (go_all) next = (L.bm0 & bit) ? (uint32_t)m.heads16[score] : PS_NIL16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bool go = go_all && nk[j] <= nl[j];
+        const uint32_t idx = slot16(L, go);
+        if (go) {
+            Entry16 e; e.k = nk[j]; e.l = nl[j]; e.a = wa; e.b = wb | (next << 16);
+            store16(reinterpret_cast<Entry16 *>(m.pool) + idx, e);
+            next = idx;
+        }
+        any = any || go;
+        L.n_stack += go ? 1 : 0; L.st.pushes += go ? 1u : 0u;
+    }
+    if (any) m.heads16[score] = (uint16_t)next;
+    L.bm0 |= any ? bit : 0ull;
+}
+
 // pop the newest entry of the lowest non-empty score bucket into the lane's current-entry registers
 template <bool WIDE>
 PS_HD void bt_pop(const BtArgs &a, BtLane &L, BtMem &m)
@@ -580,7 +633,45 @@ PS_HD void bt_iter(const BtArgs &a, BtLane &L, BtMem &m, int fetch_r, bool serve
             const bwtint k2 = sel4(nk, s), l2 = sel4(nl, s);
             if (k2 <= l2) occ_touch(a.ix, k2, l2, L.touch0, L.touch1);
         }
-        if (allow_diff && i >= md.indel_end_skip + tmp && len - i >= md.indel_end_skip + tmp) {
+        const bool gap_ok = allow_diff && i >= md.indel_end_skip + tmp && len - i >= md.indel_end_skip + tmp;
+        if (!WIDE) {
+            // ---- narrow stack: lean pushes ----
+            if (L.bump + 9u > a.pool_cap) { L.status = RS_OVERFLOW_POOL; L.mode = M_POP; return; }   // this tier is too small for the read
+            const bool from_m = e_st == ST_M, from_i = e_st == ST_I, from_d = e_st == ST_D;
+            // insertion child: opens from M, extends from I
+            {
+                const bool open = from_m && e_go < md.max_gapo, ext = from_i && e_ge < md.max_gape;
+                const int sc = e_sc + (open ? md.s_gapo_ins : md.s_gape), un = e_un + (open ? md.u_gapo_ins : md.u_gape);
+                const bool go = gap_ok && (open || ext) && un <= L.max_units;
+                push16(L, m, go, ek, el, e16_a(i, true, e_mm, ST_I, e_go + (open ? 1 : 0), e_ge + (open ? 0 : 1)), e16_b(e_ni + 1, e_nd, sc), sc);
+            }
+            // deletion children: open from M, extend from D; the four share score, counts and position
+            {
+                const bool open = from_m && e_go < md.max_gapo;
+                const bool ext = from_d && e_ge < md.max_gape && ((e_ge + e_go) * md.u_tight < L.max_units || occ < (bwtint)md.max_del_occ);
+                const int sc = e_sc + (open ? md.s_gapo_del : md.s_gape), un = e_un + (open ? md.u_gapo_del : md.u_gape);
+                const bool go = gap_ok && (open || ext) && un <= L.max_units;
+                push16_group(L, m, go, nk, nl, e16_a(i + 1, true, e_mm, ST_D, e_go + (open ? 1 : 0), e_ge + (open ? 0 : 1)), e16_b(e_ni, e_nd + 1, sc), sc);
+            }
+            L.mode = M_POP;
+            const bool do_mm = allow_diff && allow_M;
+#pragma unroll
+            for (int j = 1; j <= 4; ++j) {
+                const int c = (s + j) & 3;
+                const bool is_mm = (j != 4 || s > 3);
+                const bwtint k2 = sel4(nk, c), l2 = sel4(nl, c);
+                const bool ok = k2 <= l2;
+                if (j < 4 || s > 3) {       // mismatch children (the fourth only for an N in the read)
+                    const int sc = e_sc + cost_of(md.s_mm_pk, s, c), un = e_un + cost_of(md.u_mm_pk, s, c);
+                    push16(L, m, do_mm && ok && is_mm && un <= L.max_units, k2, l2, e16_a(i, true, e_mm + 1, ST_M, e_go, e_ge), e16_b(e_ni, e_nd, sc), sc);
+                }
+                if (j == 4 && ok && !is_mm && (do_mm || s < 4)) {   // the match child: parent's score, pushed last => the next pop
+                    L.k = k2; L.l = l2; L.i = i; L.state = ST_M; L.ldp = 0; L.have_cur = true;
+                }
+            }
+            return;
+        }
+        if (gap_ok) {
             if (e_st == ST_M) {
                 if (e_go < md.max_gapo) {
                     bt_push<WIDE>(a, L, m, true, i, ek, el, e_mm, e_go + 1, e_ge, e_ni + 1, e_nd, ST_I, true, e_sc + md.s_gapo_ins, e_un + md.u_gapo_ins);

@@ -181,7 +181,7 @@ static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases
     { EvTimer t(s); launch_width(wa, s); PS_HIP(hipGetLastError()); b.tm.ms_width += t.stop(); ++b.tm.n_width_launches; }
     int dev_cus = 256;
     { hipDeviceProp_t p; if (hipGetDeviceProperties(&p, ctx->device) == hipSuccess && p.multiProcessorCount > 0) dev_cus = p.multiProcessorCount; }
-    const bool wide = pool_cap > 65535;                       // narrow entries link with 16-bit indices
+    const bool wide = pool_cap > 65535 || md.n_buckets > 64;  // narrow entries link with 16-bit indices and keep one 64-bit bucket bitmap
     const int lm = lm_bytes(len, seed_len, md.n_buckets, wide);
     int per_cu = (int)((size_t)(160 * 1024) / ((size_t)256 * lm));
     if (per_cu < 1) throw Error("read length / score range too large for the per-lane LDS state");
