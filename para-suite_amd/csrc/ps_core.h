@@ -149,25 +149,6 @@ PS_HD void occ_pair1(const IndexView &ix, bwtint k, bwtint l, int c, uint32_t &o
     if (need_k && !other) ++st.same;
 }
 
-// Touch the two Occ blocks a lane will need in its NEXT iteration (one dword each): the lines travel to
-// the CU while the lane still pushes children / pops, so the next iteration's 64-byte loads hit near
-// caches.  The loaded words are consumed (a register-only asm) right after the next real block loads.
-PS_HD void occ_touch(const IndexView &ix, bwtint k, bwtint l, uint32_t &t0, uint32_t &t1)
-{
-    const bwtint bl = row_to_stored(ix, l) / PS_BLK_SYMS;
-    const bwtint bk = k != 0 ? row_to_stored(ix, k - 1) / PS_BLK_SYMS : bl;
-    t0 = reinterpret_cast<const uint32_t *>(ix.blocks + bl)[0];
-    t1 = reinterpret_cast<const uint32_t *>(ix.blocks + bk)[0];
-}
-PS_HD void occ_touch_consume(uint32_t t0, uint32_t t1)
-{
-#ifdef __HIP_DEVICE_COMPILE__
-    asm volatile("" :: "v"(t0), "v"(t1));
-#else
-    (void)t0; (void)t1;
-#endif
-}
-
 // ------------------------------------------------------------ read access --
 PS_HD int read_base(const uint32_t *bases, const uint32_t *nmask, int n_reads, int r, int j) // 0..3, 4 = N
 {
@@ -217,7 +198,6 @@ struct BtLane {
     unsigned long long best_cnt;
     unsigned long long bm0, bm1;  // non-empty score buckets (two scalars: a dynamically indexed array would live in scratch)
     uint32_t bump, free_head, iters0;
-    uint32_t touch0, touch1;       // words of the prefetched blocks (occ_touch)
     LaneStats st;
 };
 
@@ -585,7 +565,6 @@ PS_HD void bt_iter(const BtArgs &a, BtLane &L, BtMem &m, int fetch_r, bool serve
     // ---- the memory step, shared by both search modes: Occ(k-1,.) and Occ(l,.) -> the four child intervals ----
     uint32_t ck[4], cl[4];
     occ_pair4(a.ix, L.k, L.l, ck, cl, L.st);
-    occ_touch_consume(L.touch0, L.touch1);
     bwtint nk[4], nl[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) { nk[c] = a.ix.L2[c] + ck[c] + 1; nl[c] = a.ix.L2[c] + cl[c]; }
@@ -597,7 +576,6 @@ PS_HD void bt_iter(const BtArgs &a, BtLane &L, BtMem &m, int fetch_r, bool serve
         if (k2 > l2) { L.mode = M_POP; return; }
         L.k = k2; L.l = l2; --L.i;
         if (L.i == 0) L.mode = M_HIT;
-        else occ_touch(a.ix, k2, l2, L.touch0, L.touch1);
         return;
     }
     {
@@ -629,10 +607,6 @@ PS_HD void bt_iter(const BtArgs &a, BtLane &L, BtMem &m, int fetch_r, bool serve
         const bwtint ek = L.k, el = L.l;
         const int tmp = e_go + e_ge;
         const int s = seq_at(m, i, len);
-        if (s < 4 && i > 0) {                                  // the match child is the next entry this lane expands
-            const bwtint k2 = sel4(nk, s), l2 = sel4(nl, s);
-            if (k2 <= l2) occ_touch(a.ix, k2, l2, L.touch0, L.touch1);
-        }
         const bool gap_ok = allow_diff && i >= md.indel_end_skip + tmp && len - i >= md.indel_end_skip + tmp;
         if (!WIDE) {
             // ---- narrow stack: lean pushes ----

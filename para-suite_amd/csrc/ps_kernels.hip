@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(256) k_backtrack(const BtArgs *__restrict__ ap
     m.pool = reinterpret_cast<uint8_t *>(a.pool) + (size_t)lane_g * a.pool_cap * (WIDE ? sizeof(Entry) : sizeof(Entry16));
     m.heads = WIDE ? a.heads + (size_t)lane_g * PS_MAX_BUCKETS : nullptr;
     BtLane L;
-    L.mode = M_FETCH; L.r = 0; L.have_cur = false; L.n_stack = 0; L.status = RS_OK; L.n_aln = 0; L.touch0 = L.touch1 = 0;
+    L.mode = M_FETCH; L.r = 0; L.have_cur = false; L.n_stack = 0; L.status = RS_OK; L.n_aln = 0;
     L.st = {0, 0, 0, 0, 0, 0, 0, 0};
     // Reads are handed out dynamically: search effort differs by orders of magnitude between reads, so a
     // lane takes a new read as soon as it is done.  A wave reserves chunks of PS_Q_CHUNK reads from one

@@ -125,6 +125,28 @@ std::unique_ptr<Batch> batch_create(Ctx *ctx, ReadSet &&rs_in)
     for (Bin &bin : b->bins) {
         std::string err;
         if (!make_model(ctx->opt, bin.len, bin.md, err)) throw Error(err);
+        // Order the reads of a bin by their leading bases (the search consumes a read from its first base): the
+        // lanes of a wave then walk the same top levels of the BWT, so their Occ loads coalesce and hit in cache.
+        // Results return to input order through ids[]; the order inside a bin is free.
+        {
+            const size_t n = bin.ids.size();
+            const int kb = bin.len < 16 ? bin.len : 16;
+            std::vector<uint32_t> key(n), key2(n); std::vector<int32_t> id2(n);
+            for (size_t r = 0; r < n; ++r) {
+                const uint8_t *sq = rs.seq.data() + rs.off[bin.ids[r]];
+                uint32_t k = 0;
+                for (int j = 0; j < kb; ++j) k = (k << 2) | (uint32_t)(sq[j] & 3);
+                key[r] = k << (2 * (16 - kb));
+            }
+            for (int sh = 0; sh < 32; sh += 8) {                     // LSD radix sort, stable
+                size_t cnt[257] = {0};
+                for (size_t r = 0; r < n; ++r) ++cnt[((key[r] >> sh) & 0xff) + 1];
+                for (int d = 0; d < 256; ++d) cnt[d + 1] += cnt[d];
+                for (size_t r = 0; r < n; ++r) { const size_t p = cnt[(key[r] >> sh) & 0xff]++; key2[p] = key[r]; id2[p] = bin.ids[r]; }
+                key.swap(key2); bin.ids.swap(id2);
+            }
+            for (size_t r = 0; r < n; ++r) b->read_local[bin.ids[r]] = (int32_t)r;
+        }
         const size_t n = bin.ids.size();
         bin.n_bw = (bin.len + 15) / 16; bin.n_mw = (bin.len + 31) / 32;
         bin.h_bases.assign((size_t)bin.n_bw * n, 0); bin.h_nmask.assign((size_t)bin.n_mw * n, 0);
