@@ -62,3 +62,14 @@ def sam_records(path):
 
 def sam_sq(path):
     return [l for l in open(path).read().split("\n") if l.startswith("@SQ")]
+
+
+@pytest.fixture(scope="session")
+def mid(workdir):
+    """8 Mbp, four contigs: deep enough that SA intervals stay non-empty for ~11 levels (more search per read)"""
+    import orc
+    import simulate as S
+    g = S.big_genome(8_000_000, 4, seed=0x5EED0007)
+    fa = os.path.join(workdir, "mid.fa")
+    S.write_fasta(fa, g)
+    return dict(genome=g, fa=fa, orc_index=orc.Index.from_fasta(fa))

@@ -145,3 +145,50 @@ def test_empty_and_degenerate_reads(ctx_example, example, workdir):
         f.write("@one\nA\n+\nI\n")
     ctx_example.set_stock("0.04")
     _compare(ctx_example, example["orc_index"], orc.stock_opt("0.04"), fq, workdir, "degenerate")
+
+
+@pytest.fixture(scope="module")
+def ctx_mid(mid):
+    import capi
+    return capi.Ctx.build(mid["fa"])
+
+
+def test_index_mid_genome(ctx_mid, mid):
+    _check_index(ctx_mid, mid["orc_index"])
+
+
+@pytest.mark.parametrize("read_len,mode", [(36, "stock"), (75, "stock"), (100, "stock"), (36, "profile"), (75, "profile"), (100, "profile")])
+def test_lengths_and_modes_mid_genome(ctx_mid, mid, workdir, read_len, mode):
+    """the read lengths of BASELINE.json configs[4] (36-75 bp) and 100 bp, both cost models, 8 Mbp genome"""
+    import orc
+    import simulate as S
+    fq = _fastq(mid["genome"], workdir, "mid_%d" % read_len, n_reads=4000, read_len=read_len, seed=100 + read_len, indel_scale=4.0)
+    if mode == "stock":
+        ctx_mid.set_stock("0.04")
+        opt = orc.stock_opt("0.04")
+    else:
+        P = S.EXAMPLE_PROFILE.copy()
+        P[3, 1], P[3, 3] = 0.12, 0.87
+        ctx_mid.set_profile(P, 2.1e-5, 5.9e-4, -1)
+        opt = orc.profile_opt(P, 2.1e-5, 5.9e-4, -1)
+    b = _compare(ctx_mid, mid["orc_index"], opt, fq, workdir, "mid_%d_%s" % (read_len, mode), n_check_alns=200)
+    h = b.hits()
+    assert (h["type"] != 0).mean() > 0.8
+
+
+def test_reference_accuracy_rule(ctx_mid, mid, workdir):
+    """the reference's own acceptance rule for simulated reads (ValidateBenchmarkStatisticsPARCLIP.java:145-159:
+    same chromosome, start-5 <= alignmentStart, end+5 >= alignmentEnd) on the product's SAM"""
+    import simulate as S
+    sim = S.simulate_reads(mid["genome"], 6000, 50, seed=321, indel_scale=1.0)
+    fq = os.path.join(workdir, "acc.fq")
+    S.write_fastq(fq, sim)
+    P = S.EXAMPLE_PROFILE.copy()
+    P[3, 1], P[3, 3] = 0.12, 0.87
+    ctx_mid.set_profile(P, 2.1e-5, 5.9e-4, -1)
+    b = ctx_mid.batch_from_fastq(fq)
+    b.run(4)
+    sam = os.path.join(workdir, "acc.sam")
+    b.write_sam(sam)
+    mapped, correct, total = S.score_truth(sam)
+    assert total == 6000 and mapped > 0.9 * total and correct > 0.99 * mapped
