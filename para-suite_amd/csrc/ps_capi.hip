@@ -32,6 +32,7 @@ static ps_ctx *new_ctx(int device)
     x->c.device = device;
     PS_HIP(hipStreamCreateWithFlags(&x->c.stream, hipStreamNonBlocking));
     if (const char *e = std::getenv("PS_FETCH_MIN")) x->c.fetch_min = std::atoi(e);       // tuning knobs
+    if (const char *e = std::getenv("PS_N_BIG")) x->c.n_big = std::atoi(e);
     if (const char *e = std::getenv("PS_HIT_MIN")) x->c.hit_min = std::atoi(e);
     if (std::getenv("PS_READ_ITERS")) x->c.want_read_iters = true;
     if (const char *e = std::getenv("PS_BT_BLOCKS")) x->c.bt_blocks = std::atoi(e);

@@ -186,7 +186,8 @@ PS_HD void wchain_step(const IndexView &ix, WChain &c, int base, uint32_t &w_out
 // ----------------------------------------------------- backtracking lane ---
 static const int PS_POP_TRIES = 1;   // retrying rejected pops inside one iteration was measured: the whole wave pays for the
                                      // extra pop passes (profile mode +21 % time), so one pop per iteration
-enum { M_FETCH = 0, M_POP = 1, M_EXACT = 2, M_EXPAND = 3, M_EXIT = 4, M_HIT = 5 };
+enum { M_FETCH = 0, M_POP = 1, M_EXACT = 2, M_EXPAND = 3, M_EXIT = 4, M_HIT = 5,
+       M_GROW = 6 };   // the lane's private stack is full: the wave moves it to a large slot (kernel), then the expansion is redone
 
 struct BtLane {
     int r, mode;
@@ -198,6 +199,7 @@ struct BtLane {
     unsigned long long best_cnt;
     unsigned long long bm0, bm1;  // non-empty score buckets (two scalars: a dynamically indexed array would live in scratch)
     uint32_t bump, free_head, iters0;
+    uint32_t cap;                  // capacity of the stack this lane currently uses (private slice, or a large slot after M_GROW)
     LaneStats st;
 };
 
@@ -513,7 +515,7 @@ PS_COLD bool bt_fetch(const BtArgs &a, BtLane &L, BtMem &m, int fetch_r)
         if (nNu > md.max_units) { bt_finish_read(a, L); return false; }
         L.k = 0; L.l = a.ix.seq_len; L.i = len; L.score = 0; L.units = 0;
         L.n_mm = L.n_gapo = L.n_gape = L.n_ins = L.n_del = 0; L.state = ST_M; L.ldp = 0;
-        L.have_cur = true; L.n_stack = 0; L.bm0 = L.bm1 = 0; L.bump = 0; L.free_head = PS_NIL;
+        L.have_cur = true; L.n_stack = 0; L.bm0 = L.bm1 = 0; L.bump = 0; L.free_head = PS_NIL; L.cap = a.pool_cap;
         L.best_score = 1 << 29; L.max_units = md.max_units; L.best_cnt = 0;
         return true;
 }
@@ -527,7 +529,7 @@ PS_HD void bt_iter(const BtArgs &a, BtLane &L, BtMem &m, int fetch_r, bool serve
 {
     const Model &md = a.md;
     const int len = a.len;
-    if (L.mode == M_EXIT) return;          // retired lane: must not reach the memory step below
+    if (L.mode == M_EXIT || L.mode == M_GROW) return;   // retired lane / lane waiting for a larger stack: nothing to do here
     ++L.st.iters;
     if (L.mode == M_HIT) {
         if (!serve_hit) return;
@@ -610,7 +612,10 @@ PS_HD void bt_iter(const BtArgs &a, BtLane &L, BtMem &m, int fetch_r, bool serve
         const bool gap_ok = allow_diff && i >= md.indel_end_skip + tmp && len - i >= md.indel_end_skip + tmp;
         if (!WIDE) {
             // ---- narrow stack: lean pushes ----
-            if (L.bump + 9u > a.pool_cap) { L.status = RS_OVERFLOW_POOL; L.mode = M_POP; return; }   // this tier is too small for the read
+            if (L.bump + 9u > L.cap) {       // stack full: ask for a large slot once; if that is full too, the read goes to the next tier
+                if (L.cap == a.pool_cap && a.n_big) { L.mode = M_GROW; return; }
+                L.status = RS_OVERFLOW_POOL; L.mode = M_POP; return;
+            }
             const bool from_m = e_st == ST_M, from_i = e_st == ST_I, from_d = e_st == ST_D;
             // insertion child: opens from M, extends from I
             {

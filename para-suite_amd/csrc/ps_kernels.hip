@@ -84,7 +84,8 @@ __global__ void __launch_bounds__(256) k_backtrack(const BtArgs *__restrict__ ap
     BtMem m;
     uint8_t *mine = smem + (size_t)threadIdx.x * lm_stride;
     bt_mem_bind(m, mine, a.len, a.md.seed_len);
-    m.pool = reinterpret_cast<uint8_t *>(a.pool) + (size_t)lane_g * a.pool_cap * (WIDE ? sizeof(Entry) : sizeof(Entry16));
+    uint8_t *const pool_private = reinterpret_cast<uint8_t *>(a.pool) + (size_t)lane_g * a.pool_cap * (WIDE ? sizeof(Entry) : sizeof(Entry16));
+    m.pool = pool_private;
     m.heads = WIDE ? a.heads + (size_t)lane_g * PS_MAX_BUCKETS : nullptr;
     BtLane L;
     L.mode = M_FETCH; L.r = 0; L.have_cur = false; L.n_stack = 0; L.status = RS_OK; L.n_aln = 0;
@@ -100,6 +101,7 @@ __global__ void __launch_bounds__(256) k_backtrack(const BtArgs *__restrict__ ap
     bool exhausted = false;
     for (;;) {
         const bool want = L.mode == M_FETCH;
+        if (!WIDE && want) m.pool = pool_private;              // a new read starts on the lane's private stack slice
         const unsigned long long wmask = __ballot(want), lmask = __ballot(L.mode != M_EXIT), hmask = __ballot(L.mode == M_HIT);
         if (lmask == 0) break;
         const bool stalled = (wmask | hmask) == lmask;          // nobody can advance without being served
@@ -125,6 +127,25 @@ __global__ void __launch_bounds__(256) k_backtrack(const BtArgs *__restrict__ ap
                     q_next += take; served += take;
                 }
                 if (want && fetch_r < 0 && exhausted) fetch_r = a.n_reads;   // nothing left: this lane retires
+            }
+        }
+        if (!WIDE) {
+            unsigned long long gmask = __ballot(L.mode == M_GROW);
+            while (gmask) {                                    // wave-uniform loop over the lanes that need a larger stack
+                const int src = __ffsll((unsigned long long)gmask) - 1;
+                gmask &= gmask - 1;
+                unsigned int slot = 0;
+                if (lane == src) slot = atomicAdd(a.big_next, 1u);
+                slot = (unsigned int)__shfl((int)slot, src, 64);
+                const unsigned int n_copy = (unsigned int)__shfl((int)L.bump, src, 64);
+                const unsigned long long from = (unsigned long long)__shfl((long long)reinterpret_cast<unsigned long long>(m.pool), src, 64);
+                if (slot < a.n_big) {
+                    const uint4 *sp = reinterpret_cast<const uint4 *>(from);
+                    uint4 *dp = reinterpret_cast<uint4 *>(a.big_pool + (size_t)slot * a.big_cap * sizeof(Entry16));
+                    for (unsigned int e = (unsigned int)lane; e < n_copy; e += 64u) dp[e] = sp[e];
+                    __threadfence();                           // the copies of all lanes are visible before the owner pops from them
+                    if (lane == src) { m.pool = dp; L.cap = a.big_cap; L.mode = M_EXPAND; }
+                } else if (lane == src) { L.status = RS_OVERFLOW_POOL; L.mode = M_POP; }
             }
         }
         bt_iter<WIDE>(a, L, m, fetch_r, serve_hit);

@@ -227,6 +227,11 @@ static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases
     a.alns = alns; a.aln_cap = aln_cap; a.n_aln = n_aln; a.status = status;
     a.pool = pool; a.pool_cap = pool_cap; a.heads = heads; a.wide = wide ? 1 : 0; a.stats = b.d_stats.p + 1;
     a.queue = queue; a.fetch_min = ctx->fetch_min; a.hit_min = ctx->hit_min;
+    if (!wide && pool_cap < 65535 && ctx->n_big > 0) {         // large slots for the reads that outgrow their private slice
+        a.big_cap = 65535; a.n_big = (uint32_t)std::min<int64_t>(ctx->n_big, std::max(64, n));
+        a.big_pool = ctx->ws_get<uint8_t>("big_pool", (size_t)a.n_big * a.big_cap * 16);
+        a.big_next = queue + 4;                                  // second counter in the zeroed queue words
+    }
     uint32_t *riters = nullptr;
     if (ctx->want_read_iters) { riters = ctx->ws_get<uint32_t>("riters", n); PS_HIP(hipMemsetAsync(riters, 0, (size_t)n * 4, s)); a.read_iters = riters; }
     { EvTimer t(s); launch_backtrack(a, ctx->ws_get<BtArgs>("btargs", 1), blocks, lm, s); PS_HIP(hipGetLastError()); b.tm.ms_backtrack += t.stop(); ++b.tm.n_backtrack_launches; }

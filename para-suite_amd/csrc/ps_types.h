@@ -99,6 +99,9 @@ struct BtArgs {
     void *pool; uint32_t pool_cap;                    // per lane: pool_cap entries (16 B narrow / 32 B wide)
     uint32_t *heads;                                  // wide stack only: heads[lane*PS_MAX_BUCKETS + bucket]
     int wide;
+    // large stack slots for the few reads that outgrow their private slice (narrow stack only): taken with one
+    // atomic, the private entries are copied over by the whole wave, indices stay valid
+    uint8_t *big_pool; uint32_t big_cap, n_big; uint32_t *big_next;
     uint32_t *queue;                                  // next unassigned read (waves take chunks of it)
     uint32_t *read_iters;                             // optional: iterations spent per read (profiling aid)
     int hit_min;                                      // lanes with a pending hit a wave collects before it records them

@@ -59,7 +59,7 @@ uint32_t hs_sa(void *p, uint64_t row)
 
 // Width stage + backtracking stage for n_reads reads of one length, simulated with n_lanes lanes.
 // codes: [n_reads][len] (0..3, 4 = N).  Outputs: w_out [len+1][n_reads] (pre-shadow), cwb, alns.
-int hs_aln(void *p, const Model *md, int n_reads, int len, const uint8_t *codes, int n_lanes, int pool_cap, int aln_cap, int force_wide,
+int hs_aln(void *p, const Model *md, int n_reads, int len, const uint8_t *codes, int n_lanes, int pool_cap, int aln_cap, int force_wide, int n_big,
            uint32_t *w_out, uint8_t *cwb_out, uint8_t *cswb_out, AlnRec *alns, int32_t *n_aln, uint8_t *status, KStats *ks)
 {
     SimIndex *s = (SimIndex *)p;
@@ -101,7 +101,11 @@ int hs_aln(void *p, const Model *md, int n_reads, int len, const uint8_t *codes,
     std::vector<uint8_t> pool((size_t)n_lanes * pool_cap * (wide ? sizeof(Entry) : sizeof(Entry16)));
     std::vector<uint32_t> heads((size_t)n_lanes * PS_MAX_BUCKETS);
     a.pool = pool.data(); a.pool_cap = (uint32_t)pool_cap; a.heads = heads.data(); a.wide = wide;
+    const uint32_t big_cap = 65535;
+    std::vector<std::vector<uint8_t>> big_slots;            // large stacks handed out on M_GROW (the kernel uses one arena + an atomic)
+    a.n_big = wide ? 0 : (uint32_t)n_big; a.big_cap = big_cap;
     int lmb = lm_bytes(len, seed_len, md->n_buckets, wide);
+    std::vector<uint8_t *> cur_pool(n_lanes, nullptr);
     std::vector<uint8_t> lm((size_t)n_lanes * lmb);
     std::vector<BtLane> lanes(n_lanes); std::vector<int> next(n_lanes);
     for (int t = 0; t < n_lanes; ++t) { memset(&lanes[t], 0, sizeof(BtLane)); lanes[t].mode = M_FETCH; next[t] = t; }
@@ -113,7 +117,16 @@ int hs_aln(void *p, const Model *md, int n_reads, int len, const uint8_t *codes,
             if (L.mode == M_EXIT) { BtMem mm{}; bt_iter<false>(a, L, mm, -1, true); continue; }   // the kernel calls retired lanes too: must be a no-op
             BtMem m; uint8_t *mine = lm.data() + (size_t)t * lmb;
             bt_mem_bind(m, mine, len, seed_len);
-            m.pool = pool.data() + (size_t)t * pool_cap * (wide ? sizeof(Entry) : sizeof(Entry16));
+            uint8_t *priv = pool.data() + (size_t)t * pool_cap * (wide ? sizeof(Entry) : sizeof(Entry16));
+            if (L.mode == M_FETCH || !cur_pool[t]) cur_pool[t] = priv;
+            if (L.mode == M_GROW) {                          // what the kernel does wave-cooperatively
+                if (big_slots.size() < a.n_big) {
+                    big_slots.emplace_back((size_t)big_cap * sizeof(Entry16));
+                    memcpy(big_slots.back().data(), cur_pool[t], (size_t)L.bump * sizeof(Entry16));
+                    cur_pool[t] = big_slots.back().data(); L.cap = big_cap; L.mode = M_EXPAND;
+                } else { L.status = RS_OVERFLOW_POOL; L.mode = M_POP; }
+            }
+            m.pool = cur_pool[t];
             m.heads = a.heads + (size_t)t * PS_MAX_BUCKETS;
             int fr = -1;                                   // static hand-out here; the kernel deals reads from a queue
             if (L.mode == M_FETCH) { fr = next[t] < n_reads ? next[t] : n_reads; next[t] += n_lanes; }

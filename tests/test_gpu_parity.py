@@ -132,7 +132,7 @@ def test_small_tiers_escalate(ctx_example, example, workdir):
         b = _compare(ctx_example, example["orc_index"], orc.stock_opt("0.04"), fq, workdir, "tiers")
         assert b.timing()["n_overflow_tier1"] > 0
     finally:
-        ctx_example.set_tiers(pool_cap=[1024, 32768, 2000064], aln_cap=[8, 256, 65536], bt_blocks=0)
+        ctx_example.set_tiers(pool_cap=[16384, 65535, 2000064], aln_cap=[8, 256, 65536], bt_blocks=0)
 
 
 def test_empty_and_degenerate_reads(ctx_example, example, workdir):
@@ -192,3 +192,17 @@ def test_reference_accuracy_rule(ctx_mid, mid, workdir):
     b.write_sam(sam)
     mapped, correct, total = S.score_truth(sam)
     assert total == 6000 and mapped > 0.9 * total and correct > 0.99 * mapped
+
+
+def test_stack_growth_in_launch(ctx_example, example, workdir):
+    """a private stack slice of 64 entries: almost every read moves to a large slot inside the launch
+    (wave-cooperative copy) and none needs the next tier; results unchanged"""
+    import orc
+    fq = _fastq(example["genome"], workdir, "grow", n_reads=1500, read_len=50, seed=15, indel_scale=30)
+    ctx_example.set_stock("0.04")
+    ctx_example.set_tiers(pool_cap=[64, 65535, 2000064], aln_cap=[8, 256, 65536], bt_blocks=0)
+    try:
+        b = _compare(ctx_example, example["orc_index"], orc.stock_opt("0.04"), fq, workdir, "grow")
+        assert b.timing()["n_overflow_tier1"] == 0
+    finally:
+        ctx_example.set_tiers(pool_cap=[16384, 65535, 2000064], aln_cap=[8, 256, 65536], bt_blocks=0)

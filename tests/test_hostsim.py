@@ -32,7 +32,7 @@ def hs():
     H.hs_sizeof_alnrec.restype = C.c_size_t
     H.hs_model_stock.argtypes = [C.c_char_p, C.c_int, C.c_void_p]
     H.hs_model_profile.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int, C.c_void_p]
-    H.hs_aln.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 7
+    H.hs_aln.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 7
     H.hs_banded.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_int]
     assert H.hs_sizeof_alnrec() == ALNREC.itemsize
     return H
@@ -59,14 +59,14 @@ def test_occ_blocks_and_sa_walk(hs, sim_index, example):
         assert hs.hs_sa(sim_index, int(k)) == ix.sa(int(k)) & 0xFFFFFFFF
 
 
-def _run(hs, h, model, codes, n_lanes=64, pool_cap=4096, aln_cap=64, wide=0):
+def _run(hs, h, model, codes, n_lanes=64, pool_cap=4096, aln_cap=64, wide=0, n_big=0):
     n, L = codes.shape
     alns = np.zeros((n, aln_cap), dtype=ALNREC)
     n_aln = np.zeros(n, dtype=np.int32)
     status = np.zeros(n, dtype=np.uint8)
     ks = np.zeros(8, dtype=np.uint64)
     cc = np.ascontiguousarray(codes)
-    hs.hs_aln(h, model, n, L, cc.ctypes.data, n_lanes, pool_cap, aln_cap, wide, None, None, None, alns.ctypes.data,
+    hs.hs_aln(h, model, n, L, cc.ctypes.data, n_lanes, pool_cap, aln_cap, wide, n_big, None, None, None, alns.ctypes.data,
               n_aln.ctypes.data, status.ctypes.data, ks.ctypes.data)
     return alns, n_aln, status, ks
 
@@ -124,6 +124,16 @@ def test_wide_stack_variant(hs, sim_index, example):
     model = (C.c_uint8 * hs.hs_sizeof_model())()
     assert hs.hs_model_stock(b"0.04", 50, model) == 0
     _compare(hs, sim_index, example["orc_index"], orc.stock_opt("0.04"), model, sim["codes"], wide=1, pool_cap=4096)
+
+
+def test_stack_grows_into_large_slot(hs, sim_index, example):
+    """a read that outgrows its private stack slice continues in a large slot (entries copied, indices kept)"""
+    sim = S.simulate_reads(example["genome"], 200, 50, seed=23, indel_scale=40)
+    model = (C.c_uint8 * hs.hs_sizeof_model())()
+    assert hs.hs_model_stock(b"0.04", 50, model) == 0
+    _compare(hs, sim_index, example["orc_index"], orc.stock_opt("0.04"), model, sim["codes"], pool_cap=24, n_big=1000)
+    _, _, status, _ = _run(hs, sim_index, model, sim["codes"], pool_cap=24, n_big=3)
+    assert (status == 1).any() and (status == 0).any()       # slots exhausted: the rest is reported for the next tier
 
 
 def test_pool_overflow_is_reported(hs, sim_index, example):
