@@ -1,5 +1,6 @@
 // ps_capi.hip -- extern "C" boundary (include/parasuite_hip.h).  Exceptions stop here.
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -173,7 +174,7 @@ ps_batch *ps_batch_from_fastq(ps_ctx *x, const char *fastq)
 {
     PS_TRY
         require_device(x->c.device);
-        ReadSet rs; load_reads(fastq, rs);
+        ReadSet rs; load_reads(fastq, rs, x->c.host_threads);
         ps_batch *b = new ps_batch();
         b->b = batch_create(&x->c, std::move(rs));
         return b;
@@ -272,14 +273,35 @@ int ps_map(int threads, const char *mm, const char *error_profile, const char *i
            const char *ref_fa, const char *fastq, const char *out_sam)
 {
     PS_TRY
+        const bool verbose = std::getenv("PS_VERBOSE") != nullptr;
+        auto t0 = std::chrono::steady_clock::now();
+        auto lap = [&](const char *what) {
+            if (!verbose) return;
+            auto t1 = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "[parasuite-hip] %-28s %.3f s\n", what, std::chrono::duration<double>(t1 - t0).count());
+            t0 = t1;
+        };
         ps_ctx *x = index_files_exist(ref_fa) ? ps_ctx_open(ref_fa, 0) : ps_ctx_build(ref_fa, 0, 1);
         if (!x) return 1;
+        lap("index resident");
         int rc = error_profile && error_profile[0] ? ps_ctx_set_profile(x, error_profile, indel_profile, mm)
                                                    : ps_ctx_set_stock(x, mm && mm[0] ? mm : "0.04");
-        ps_batch *b = rc ? nullptr : ps_batch_from_fastq(x, fastq);
-        if (!rc && !b) rc = 1;
+        x->c.host_threads = threads > 0 ? threads : 1;
+        ps_batch *b = nullptr;
+        if (!rc) {
+            try {
+                require_device(x->c.device);
+                ReadSet rs; load_reads(fastq, rs, x->c.host_threads);
+                lap("reads parsed");
+                b = new ps_batch();
+                b->b = batch_create(&x->c, std::move(rs));
+                lap("reads packed + uploaded");
+            } catch (const std::exception &e) { delete b; b = nullptr; rc = fail(e.what()); }
+        }
         if (!rc) rc = ps_batch_run(b, threads);
+        if (!rc) lap("mapped (GPU stages)");
         if (!rc) rc = ps_batch_write_sam(b, out_sam, 1, threads);
+        if (!rc) lap("SAM written");
         ps_batch_free(b); ps_ctx_close(x);
         return rc;
     PS_CATCH_INT

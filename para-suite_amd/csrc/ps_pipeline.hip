@@ -44,19 +44,13 @@ static inline uint8_t code_of(int ch)
 }
 
 // FASTQ / FASTA; read name = header up to the first white space, a trailing /1 or /2 removed
-void load_reads(const char *path, ReadSet &rs)
+// one parser pass over buf[i0, i1): appends to rs (offsets relative to rs's own arrays)
+static void parse_reads_range(const char *buf, size_t i0, size_t i1, ReadSet &rs, bool &any_qual)
 {
-    FILE *f = std::fopen(path, "rb");
-    if (!f) throw Error(std::string("cannot open reads ") + path);
-    std::fseek(f, 0, SEEK_END); long sz = std::ftell(f); std::fseek(f, 0, SEEK_SET);
-    std::vector<char> buf((size_t)sz + 1);
-    if (sz && std::fread(buf.data(), 1, (size_t)sz, f) != (size_t)sz) { std::fclose(f); throw Error(std::string("short read on ") + path); }
-    std::fclose(f);
-    const size_t n = (size_t)sz;
-    rs = ReadSet();
-    rs.off.push_back(0); rs.name_off.push_back(0);
-    size_t i = 0;
-    bool any_qual = false;
+    static uint8_t lut[256]; static bool lut_ok = false;
+    if (!lut_ok) { for (int c = 0; c < 256; ++c) lut[c] = code_of(c); lut_ok = true; }
+    size_t i = i0;
+    const size_t n = i1;
     while (i < n) {
         while (i < n && buf[i] != '@' && buf[i] != '>') ++i;
         if (i >= n) break;
@@ -65,24 +59,103 @@ void load_reads(const char *path, ReadSet &rs)
         while (i < n && !std::isspace((unsigned char)buf[i])) ++i;
         size_t nl = i - s;
         if (nl > 2 && buf[s + nl - 2] == '/' && (buf[s + nl - 1] == '1' || buf[s + nl - 1] == '2')) nl -= 2;
-        rs.names.insert(rs.names.end(), buf.data() + s, buf.data() + s + nl);
+        rs.names.insert(rs.names.end(), buf + s, buf + s + nl);
         rs.name_off.push_back((int64_t)rs.names.size());
-        while (i < n && buf[i] != '\n') ++i;
-        ++i;
-        size_t before = rs.seq.size();
-        while (i < n && buf[i] != (fq ? '+' : '>')) { if (std::isgraph((unsigned char)buf[i])) rs.seq.push_back(code_of(buf[i])); ++i; }
-        int32_t len = (int32_t)(rs.seq.size() - before);
+        const char *eol = (const char *)std::memchr(buf + i, '\n', n - i);
+        i = eol ? (size_t)(eol - buf) + 1 : n;
+        const size_t before = rs.seq.size();
+        const char stop = fq ? '+' : '>';
+        while (i < n && buf[i] != stop) {                         // sequence lines
+            eol = (const char *)std::memchr(buf + i, '\n', n - i);
+            size_t e = eol ? (size_t)(eol - buf) : n, e2 = e;
+            while (e2 > i && !std::isgraph((unsigned char)buf[e2 - 1])) --e2;     // trailing CR / blanks
+            const size_t at = rs.seq.size();
+            rs.seq.resize(at + (e2 - i));
+            for (size_t j = i; j < e2; ++j) rs.seq[at + (j - i)] = lut[(unsigned char)buf[j]];
+            i = e < n ? e + 1 : n;
+        }
+        const int32_t len = (int32_t)(rs.seq.size() - before);
         rs.len.push_back(len);
         rs.off.push_back((int64_t)rs.seq.size());
-        size_t qbefore = rs.qual.size();
+        const size_t qbefore = rs.qual.size();
         if (fq && i < n) {
-            while (i < n && buf[i] != '\n') ++i;
-            ++i;
-            while (i < n && (int32_t)(rs.qual.size() - qbefore) < len) { if (std::isgraph((unsigned char)buf[i])) rs.qual.push_back(buf[i]); ++i; }
+            eol = (const char *)std::memchr(buf + i, '\n', n - i);
+            i = eol ? (size_t)(eol - buf) + 1 : n;
+            while (i < n && (int32_t)(rs.qual.size() - qbefore) < len) {           // quality lines
+                eol = (const char *)std::memchr(buf + i, '\n', n - i);
+                size_t e = eol ? (size_t)(eol - buf) : n, e2 = e;
+                while (e2 > i && !std::isgraph((unsigned char)buf[e2 - 1])) --e2;
+                size_t take = e2 - i, room = (size_t)len - (rs.qual.size() - qbefore);
+                if (take > room) take = room;
+                rs.qual.insert(rs.qual.end(), buf + i, buf + i + take);
+                i = e < n ? e + 1 : n;
+            }
             any_qual = true;
         }
         rs.qual.resize(qbefore + (size_t)len, '!');
         ++rs.n;
+    }
+}
+
+// FASTQ / FASTA; read name = header up to the first white space, a trailing /1 or /2 removed.  Four-line FASTQ is
+// cut at record boundaries (a line starting with '@' whose second next line starts with '+') and parsed by `threads`.
+void load_reads(const char *path, ReadSet &rs, int threads)
+{
+    FILE *f = std::fopen(path, "rb");
+    if (!f) throw Error(std::string("cannot open reads ") + path);
+    std::fseek(f, 0, SEEK_END); long sz = std::ftell(f); std::fseek(f, 0, SEEK_SET);
+    std::vector<char> buf((size_t)sz + 1);
+    if (sz && std::fread(buf.data(), 1, (size_t)sz, f) != (size_t)sz) { std::fclose(f); throw Error(std::string("short read on ") + path); }
+    std::fclose(f);
+    const size_t n = (size_t)sz;
+    const char *b = buf.data();
+    if (threads < 1) threads = 1;
+    if (threads > 64) threads = 64;
+    std::vector<size_t> cut(1, 0);
+    if (threads > 1 && n > (size_t)(1 << 20) && b[0] == '@') {
+        auto next_line = [&](size_t i) { const char *e = (const char *)std::memchr(b + i, '\n', n - i); return e ? (size_t)(e - b) + 1 : n; };
+        for (int t = 1; t < threads; ++t) {
+            size_t i = next_line(n / threads * t);
+            for (int tries = 0; tries < 8 && i < n; ++tries) {          // first line here that really starts a record
+                const size_t l1 = next_line(i), l2 = l1 < n ? next_line(l1) : n;
+                if (b[i] == '@' && l2 < n && b[l2] == '+') break;
+                i = l1;
+            }
+            if (i < n && i > cut.back()) cut.push_back(i);
+        }
+    }
+    cut.push_back(n);
+    const int parts = (int)cut.size() - 1;
+    std::vector<ReadSet> piece((size_t)parts);
+    std::vector<char> anyq((size_t)parts, 0);
+    auto work = [&](int t) {
+        ReadSet &r = piece[t];
+        r.off.push_back(0); r.name_off.push_back(0);
+        bool aq = false;
+        parse_reads_range(b, cut[t], cut[t + 1], r, aq);
+        anyq[t] = aq;
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < parts; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
+    if (parts == 1) { rs = std::move(piece[0]); rs.has_qual = anyq[0] != 0; return; }
+    rs = ReadSet();
+    size_t tn = 0, ts = 0, tq = 0, tnm = 0;
+    for (auto &r : piece) { tn += (size_t)r.n; ts += r.seq.size(); tq += r.qual.size(); tnm += r.names.size(); }
+    rs.len.reserve(tn); rs.off.reserve(tn + 1); rs.name_off.reserve(tn + 1); rs.seq.reserve(ts); rs.qual.reserve(tq); rs.names.reserve(tnm);
+    rs.off.push_back(0); rs.name_off.push_back(0);
+    bool any_qual = false;
+    for (int t = 0; t < parts; ++t) {
+        ReadSet &r = piece[t];
+        const int64_t so = (int64_t)rs.seq.size(), no = (int64_t)rs.names.size();
+        rs.len.insert(rs.len.end(), r.len.begin(), r.len.end());
+        for (int64_t k = 1; k <= r.n; ++k) { rs.off.push_back(r.off[k] + so); rs.name_off.push_back(r.name_off[k] + no); }
+        rs.seq.insert(rs.seq.end(), r.seq.begin(), r.seq.end());
+        rs.qual.insert(rs.qual.end(), r.qual.begin(), r.qual.end());
+        rs.names.insert(rs.names.end(), r.names.begin(), r.names.end());
+        rs.n += r.n; any_qual = any_qual || anyq[t];
+        r = ReadSet();
     }
     rs.has_qual = any_qual;
 }
@@ -150,12 +223,21 @@ std::unique_ptr<Batch> batch_create(Ctx *ctx, ReadSet &&rs_in)
         const size_t n = bin.ids.size();
         bin.n_bw = (bin.len + 15) / 16; bin.n_mw = (bin.len + 31) / 32;
         bin.h_bases.assign((size_t)bin.n_bw * n, 0); bin.h_nmask.assign((size_t)bin.n_mw * n, 0);
-        for (size_t r = 0; r < n; ++r) {
-            const uint8_t *s = rs.seq.data() + rs.off[bin.ids[r]];
-            for (int j = 0; j < bin.len; ++j) {
-                if (s[j] > 3) bin.h_nmask[(size_t)(j >> 5) * n + r] |= 1u << (j & 31);
-                else bin.h_bases[(size_t)(j >> 4) * n + r] |= (uint32_t)s[j] << (2 * (j & 15));
-            }
+        {
+            const int nt = std::max(1, std::min(ctx->host_threads, 64));
+            auto pack = [&](int t) {                                  // distinct reads write distinct words: no sharing
+                for (size_t r = n * t / nt; r < n * (t + 1) / nt; ++r) {
+                    const uint8_t *s = rs.seq.data() + rs.off[bin.ids[r]];
+                    for (int j = 0; j < bin.len; ++j) {
+                        if (s[j] > 3) bin.h_nmask[(size_t)(j >> 5) * n + r] |= 1u << (j & 31);
+                        else bin.h_bases[(size_t)(j >> 4) * n + r] |= (uint32_t)s[j] << (2 * (j & 15));
+                    }
+                }
+            };
+            std::vector<std::thread> th;
+            for (int t = 1; t < nt; ++t) th.emplace_back(pack, t);
+            pack(0);
+            for (auto &x : th) x.join();
         }
         bin.d_ids.alloc(n); bin.d_ids.upload(bin.ids.data(), n, ctx->stream);
         bin.bases.alloc(bin.h_bases.size()); bin.nmask.alloc(bin.h_nmask.size());

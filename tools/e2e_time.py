@@ -1,0 +1,28 @@
+"""T_e2e of the file-level ABI (what the Java times, PARAsuiteMapping.java:57,94-97): index load + map + SAM written."""
+import sys, os, time, numpy as np
+sys.path.insert(0, 'para-suite_amd'); sys.path.insert(0, '.')
+import capi, torch, bench, simulate as S
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
+mbp = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+dev = torch.device('cuda', 0)
+contigs = bench.gen_genome(torch, dev, mbp * 1_000_000, 8, 0x5EED0002)
+fa = '/tmp/e2e.fa'; fq = '/tmp/e2e.fq'
+bench.write_fasta(fa, contigs)
+rd = bench.gen_reads(torch, dev, contigs, n, 50, 0x5EED0003, indels=True)
+lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+t = time.time()
+with open(fq, 'wb') as f:                      # fixed-width records: vectorised FASTQ writer
+    name = np.char.zfill(np.arange(n).astype(str), 9).astype('S9').view(np.uint8).reshape(n, 9)
+    rec = np.empty((n, 1 + 9 + 1 + 50 + 3 + 50 + 1), dtype=np.uint8)
+    rec[:, 0] = ord('@'); rec[:, 1:10] = name; rec[:, 10] = 10; rec[:, 11:61] = lut[rd]; rec[:, 61] = 10; rec[:, 62] = ord('+'); rec[:, 63] = 10
+    rec[:, 64:114] = ord('I'); rec[:, 114] = 10
+    f.write(rec.tobytes())
+print('fastq written %.1fs' % (time.time() - t))
+t = time.time(); capi.ps_index(fa); print('ps_index %.1fs' % (time.time() - t))
+P = np.array(bench.PROFILE); P[3, 1], P[3, 3] = 0.12, 0.87
+with open('/tmp/e2e.errorprofile', 'w') as f:
+    for row in P: f.write(''.join(repr(float(v)) + '\t' for v in row) + '\n')
+open('/tmp/e2e.indelprofile', 'w').write('2.1E-5\t5.9E-4')
+for rep in range(2):
+    t = time.time(); os.environ['PS_VERBOSE']='1'; capi.ps_map(16, '-1', '/tmp/e2e.errorprofile', '/tmp/e2e.indelprofile', fa, fq, '/tmp/e2e.sam'); dt = time.time() - t
+    print('ps_map (index load + %d reads + SAM written) %.2fs = %.2f M reads/s, SAM %.0f MB' % (n, dt, n / dt / 1e6, os.path.getsize('/tmp/e2e.sam') / 1e6), flush=True)
