@@ -4,9 +4,9 @@
 One "step" = one pass of the hot path (width kernel -> backtracking kernel -> tie-break selection ->
 SA-walk kernel -> banded-DP kernel) over one batch of synthetic PAR-CLIP reads that is already
 packed and resident in HBM.  Workload at N=1: BASELINE.json configs[2] -- 10 M x 50 bp simulated
-PAR-CLIP reads, full difference-tolerant search + gapped extension -- against a synthetic genome at
-the largest scale the 32-bit round-1 index supports (--genome-mbp, default 2000 = 64 % of hg19;
-hg19 itself is not on the box and its 6.27 G-symbol BWT needs the 40-bit index).
+PAR-CLIP reads, full difference-tolerant search + gapped extension -- against a synthetic genome of
+hg19's size (--genome-mbp, default 3100 in 24 contigs: 6.2e9 BWT rows, which is why rows are 33-bit;
+hg19 itself is not on the box and there is no network to fetch it).
 N>1: one process per GPU, the FM index built on rank 0 and broadcast once with RCCL, every rank maps
 its own --reads reads (weak scaling, no data-path collective); the only exchange is one integer per
 rank that chains the tie-break RNG stream in input order.
@@ -48,6 +48,20 @@ def gen_genome(torch, dev, total_bp, n_contigs, seed):
             u = torch.rand(b - a, generator=g, device=dev)
             codes[a:b] = ((u >= AT).to(torch.uint8) + (u >= 0.5).to(torch.uint8) + (u >= 1.0 - AT).to(torch.uint8))
         if n > 400000:
+            # interspersed repeats: one 2 kb segment in every 50 kb is a copy (1 % diverged) of a segment elsewhere in
+            # the contig, so ~4 % of the genome is two-copy sequence -- reads with several equally good hits, tied
+            # suffixes for the index builder -- instead of an i.i.d. text in which every 28-mer is unique
+            slot, seg = 50_000, 2_000
+            R = n // slot - 1
+            dst = torch.arange(R, device=dev, dtype=torch.int64) * slot + 20_000
+            src = (torch.rand(R, generator=g, device=dev, dtype=torch.float64) * (n - seg - 1)).long()
+            ar = torch.arange(seg, device=dev, dtype=torch.int64)[None, :]
+            for a0 in range(0, R, 256):                 # small index tensors (large advanced-indexing calls misbehave on this stack)
+                sl = slice(a0, min(R, a0 + 256))
+                piece = codes[src[sl, None] + ar]
+                mut = torch.rand(piece.shape, generator=g, device=dev) < 0.01
+                piece = torch.where(mut, (piece + torch.randint(1, 4, piece.shape, generator=g, device=dev, dtype=torch.uint8)) & 3, piece)
+                codes[dst[sl, None] + ar] = piece
             run = 20000
             mid = int(n * 0.4)
             codes[:run // 2] = 4
@@ -145,8 +159,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU")
     ap.add_argument("--read-len", type=int, default=50)
-    ap.add_argument("--genome-mbp", type=int, default=2000)
-    ap.add_argument("--contigs", type=int, default=8)
+    ap.add_argument("--genome-mbp", type=int, default=3100)
+    ap.add_argument("--contigs", type=int, default=24)
     ap.add_argument("--workload", choices=["full", "exact"], default="full")
     ap.add_argument("--cpu-sample", type=int, default=40000, help="reads of the same workload timed on the CPU oracle (0 = skip)")
     ap.add_argument("--threads", type=int, default=0)
@@ -189,6 +203,7 @@ def main():
         write_fasta(fa, contigs)
         log("genome %.1f Mbp written in %.1fs" % (args.genome_mbp, time.time() - t0))
         t1 = time.time()
+        torch.cuda.empty_cache()                    # the suffix sorter wants most of the HBM for a genome of this size
         ctx = capi.Ctx.build(fa, device=local)
         info = ctx.info()
         log("index built in %.1fs (library %.0f ms, %d doubling rounds, %.2f GB in HBM)" %
@@ -290,15 +305,15 @@ def main():
         ach = (alg_bt / (ms_bt_step * 1e-3) if dominant_bt else alg_w / (ms_w_step * 1e-3)) / 1e9
         hits = batch.hits()
         res = {
-            "metric": "aligned reads/sec (10Mx50bp PAR-CLIP vs hg19-scale genome) on MI355X; SAM bit-exact vs CPU oracle",
+            "metric": "aligned reads/sec (10Mx50bp PAR-CLIP vs hg19-size genome) on MI355X; SAM bit-exact vs CPU oracle",
             "value": world * args.reads * args.steps / elapsed,
             "unit": "reads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / K,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u32", "data": "synthetic",
+            "dtype": "u64", "data": "synthetic",
             "config": {"workload": "configs[2]: %dx%dbp simulated PAR-CLIP reads per GPU, %s, vs %d Mbp synthetic genome "
-                                   "(hg19 scale model; 32-bit index)" % (args.reads, args.read_len,
+                                   "(hg19-size synthetic genome; 33-bit BWT rows)" % (args.reads, args.read_len,
                                    "error-profile seed + banded extension" if args.workload == "full" else "exact-match seed only",
                                    args.genome_mbp),
                        "reads_per_gpu": args.reads, "read_len": args.read_len, "genome_mbp": args.genome_mbp,
@@ -328,7 +343,7 @@ def main():
                 fq = os.path.join(tmpdir, "sample.fq")
                 S.write_fastq(fq, sim, names=["r%d" % i for i in range(ns)])
                 info = ctx.info()
-                oix = orc.Index.from_parts(fa, ctx.bwt_syms_chunked(), info.primary, ctx.fetch(1).view("<u4").astype(np.uint64))
+                oix = orc.Index.from_parts(fa, ctx.bwt_syms_chunked(), info.primary, ctx.sa_samples())
                 if args.workload == "exact":
                     oopt = orc.stock_opt("0")
                 elif args.penalty == "stock":

@@ -74,9 +74,9 @@ int       ps_batch_locate(ps_batch *);                               /* SA walk 
 int       ps_batch_run(ps_batch *, int threads);                     /* the four stages above, single process */
 int       ps_batch_write_sam(ps_batch *, const char *path, int with_header, int threads);
 
-typedef struct { uint32_t k, l; uint16_t score, units; uint8_t n_mm, n_gapo, n_gape, n_ins, n_del, pad[3]; } ps_aln;
+typedef struct { uint64_t k, l; uint16_t score, units; uint8_t n_mm, n_gapo, n_gape, n_ins, n_del, pad[7]; } ps_aln;   /* 32 B */
 typedef struct {
-    int64_t pos; uint32_t sa; int32_t type, strand, mapq, n_mm, n_gapo, n_gape, ref_shift, score, c1, c2,
+    int64_t pos; uint64_t sa; int32_t type, strand, mapq, n_mm, n_gapo, n_gape, ref_shift, score, c1, c2,
             n_cigar, n_multi; uint32_t cigar[16];
 } ps_hit;
 typedef struct {

@@ -32,9 +32,9 @@ class KStats(C.Structure):
                                           "exact_steps")]
 
 
-ALN_DTYPE = np.dtype([("k", "<u4"), ("l", "<u4"), ("score", "<u2"), ("units", "<u2"), ("n_mm", "u1"), ("n_gapo", "u1"),
-                      ("n_gape", "u1"), ("n_ins", "u1"), ("n_del", "u1"), ("pad", "u1", 3)])
-HIT_DTYPE = np.dtype([("pos", "<i8"), ("sa", "<u4"), ("type", "<i4"), ("strand", "<i4"), ("mapq", "<i4"), ("n_mm", "<i4"),
+ALN_DTYPE = np.dtype([("k", "<u8"), ("l", "<u8"), ("score", "<u2"), ("units", "<u2"), ("n_mm", "u1"), ("n_gapo", "u1"),
+                      ("n_gape", "u1"), ("n_ins", "u1"), ("n_del", "u1"), ("pad", "u1", 7)])
+HIT_DTYPE = np.dtype([("pos", "<i8"), ("sa", "<u8"), ("type", "<i4"), ("strand", "<i4"), ("mapq", "<i4"), ("n_mm", "<i4"),
                       ("n_gapo", "<i4"), ("n_gape", "<i4"), ("ref_shift", "<i4"), ("score", "<i4"), ("c1", "<i4"),
                       ("c2", "<i4"), ("n_cigar", "<i4"), ("n_multi", "<i4"), ("cigar", "<u4", 16)], align=True)
 
@@ -181,6 +181,16 @@ class Ctx:
         _, n = self.blob(which)
         out = np.empty(n, dtype=np.uint8)
         _chk(lib().ps_ctx_fetch(self.h, which, out.ctypes.data, n))
+        return out
+
+    def sa_samples(self):
+        """Sampled suffix array as uint64: blob 1 holds n_sa low words followed by the bit-32 plane; entry 0 means -1."""
+        n_sa = int(self.info().n_sa)
+        w = self.fetch(1).view("<u4")
+        out = w[:n_sa].astype(np.uint64)
+        hi = (w[n_sa:, None] >> np.arange(32, dtype=np.uint32)[None, :]) & 1
+        out |= hi.reshape(-1)[:n_sa].astype(np.uint64) << np.uint64(32)
+        out[0] = np.uint64(0xFFFFFFFFFFFFFFFF)
         return out
 
     def export_blob(self, which, dev_ptr, nbytes):

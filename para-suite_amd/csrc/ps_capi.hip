@@ -117,7 +117,7 @@ int ps_ctx_blob(ps_ctx *x, int which, void **p, uint64_t *bytes)
     PS_TRY
         Index &ix = x->c.ix;
         if (which == 0) { *p = ix.blocks.p; *bytes = ix.blocks.n * sizeof(OccBlock); }
-        else if (which == 1) { *p = ix.sa.p; *bytes = ix.sa.n * sizeof(bwtint); }
+        else if (which == 1) { *p = ix.sa.p; *bytes = ix.sa.n * sizeof(uint32_t); }
         else if (which == 2) { *p = ix.pac.p; *bytes = ix.pac.n; }
         else throw Error("blob index out of range");
         return 0;
@@ -140,7 +140,7 @@ ps_ctx *ps_ctx_from_blobs(const char *meta, int64_t meta_len, int device, void *
         index_meta_deserialize(std::string(meta, (size_t)meta_len), ix);
         const bwtint primary = ix.view.primary; bwtint L2[5]; std::memcpy(L2, ix.view.L2, sizeof L2);
         const size_t nb = ix.view.n_blocks, ns = ix.view.n_sa, np = (size_t)ix.ref.l_pac / 4 + 1;
-        ix.blocks.adopt((OccBlock *)ptrs[0], nb); ix.sa.adopt((bwtint *)ptrs[1], ns); ix.pac.adopt((uint8_t *)ptrs[2], np);
+        ix.blocks.adopt((OccBlock *)ptrs[0], nb); ix.sa.adopt((uint32_t *)ptrs[1], Index::sa_words(ns)); ix.pac.adopt((uint8_t *)ptrs[2], np);
         ix.ref.pac.resize(np);
         PS_HIP(hipMemcpy(ix.ref.pac.data(), ix.pac.p, np, hipMemcpyDeviceToHost));
         ix.refresh_view();
@@ -300,6 +300,11 @@ int ps_map(int threads, const char *mm, const char *error_profile, const char *i
         }
         if (!rc) rc = ps_batch_run(b, threads);
         if (!rc) lap("mapped (GPU stages)");
+        if (!rc && verbose) {
+            const Timing &t = b->b->tm;
+            std::fprintf(stderr, "[parasuite-hip]   of which: width %.0f backtrack %.0f classify %.0f rows %.0f select %.0f+%.0f sa2pos %.0f refine %.0f host_post %.0f ms; launches %d\n",
+                         t.ms_width, t.ms_backtrack, t.ms_classify, t.ms_rows, t.ms_sel_hard, t.ms_sel_easy, t.ms_sa2pos, t.ms_refine, t.ms_host_post, t.n_backtrack_launches);
+        }
         if (!rc) rc = ps_batch_write_sam(b, out_sam, 1, threads);
         if (!rc) lap("SAM written");
         ps_batch_free(b); ps_ctx_close(x);

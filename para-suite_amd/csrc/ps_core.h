@@ -100,7 +100,12 @@ PS_HD uint32_t sel4s(uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3, int c)
     return b1 ? hi : lo;
 }
 PS_HD uint32_t sel4(const uint32_t v[4], int c) { return sel4s(v[0], v[1], v[2], v[3], c); }
-PS_HD bwtint L2_of(const IndexView &ix, int c) { return sel4s(ix.L2[0], ix.L2[1], ix.L2[2], ix.L2[3], c); }
+PS_HD bwtint L2_of(const IndexView &ix, int c)
+{
+    const bool b0 = (c & 1) != 0, b1 = (c & 2) != 0;
+    const bwtint lo = b0 ? ix.L2[1] : ix.L2[0], hi = b0 ? ix.L2[3] : ix.L2[2];
+    return b1 ? hi : lo;
+}
 // cost of reading text symbol c where the (reverse-complemented) read has s: four byte lanes per read symbol
 PS_HD int cost_of(const uint32_t pk[5], int s, int c)
 {
@@ -110,41 +115,52 @@ PS_HD int cost_of(const uint32_t pk[5], int s, int c)
 
 // row (0..n) of the BW matrix of T$ -> index into the stored BWT (the '$' row is not stored)
 PS_HD bwtint row_to_stored(const IndexView &ix, bwtint row) { return row - (row >= ix.primary ? 1u : 0u); }
+// stored symbol index -> its 192-symbol block and the offset inside it (32-bit arithmetic: s < 2^33)
+PS_HD uint32_t blk_of(bwtint s, int &off)
+{
+    const uint32_t b = (uint32_t)(s >> 6) / 3u;
+    off = (int)((uint32_t)s - b * (uint32_t)PS_BLK_SYMS);
+    return b;
+}
+// interval size as the 32-bit quantity the width arrays hold: only the full range [0, n] can exceed 32 bits
+PS_HD uint32_t width32(bwtint k, bwtint l) { const bwtint w = l - k + 1; return w > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)w; }
 
 struct LaneStats { uint32_t pairs, same, nodes, pushes, pops, iters, exact, lf; };
 
 // Occ(k-1, .) and Occ(l, .) for all four symbols: the memory operation of one search step.
 PS_HD void occ_pair4(const IndexView &ix, bwtint k, bwtint l, uint32_t ck[4], uint32_t cl[4], LaneStats &st)
 {
-    bwtint sl = row_to_stored(ix, l), bl = sl / PS_BLK_SYMS;
-    bwtint sk = 0, bk = bl;
+    int ol_ = 0, ok_ = 0;
+    const uint32_t bl = blk_of(row_to_stored(ix, l), ol_);
+    uint32_t bk = bl;
     bool need_k = k != 0;
-    if (need_k) { sk = row_to_stored(ix, k - 1); bk = sk / PS_BLK_SYMS; }
+    if (need_k) bk = blk_of(row_to_stored(ix, k - 1), ok_);
     Blk xl, xk;
     load_blk(ix.blocks, bl, xl);
     bool other = need_k && bk != bl;
     if (other) load_blk(ix.blocks, bk, xk);
-    blk_count4(xl, (int)(sl - bl * PS_BLK_SYMS) + 1, cl);
+    blk_count4(xl, ol_ + 1, cl);
     if (!need_k) { ck[0] = ck[1] = ck[2] = ck[3] = 0; }
-    else if (other) blk_count4(xk, (int)(sk - bk * PS_BLK_SYMS) + 1, ck);
-    else blk_count4(xl, (int)(sk - bk * PS_BLK_SYMS) + 1, ck);
+    else if (other) blk_count4(xk, ok_ + 1, ck);
+    else blk_count4(xl, ok_ + 1, ck);
     ++st.pairs;
     if (need_k && !other) ++st.same;
 }
 PS_HD void occ_pair1(const IndexView &ix, bwtint k, bwtint l, int c, uint32_t &ok, uint32_t &ol, LaneStats &st)
 {
-    bwtint sl = row_to_stored(ix, l), bl = sl / PS_BLK_SYMS;
-    bwtint sk = 0, bk = bl;
+    int ol_ = 0, ok_ = 0;
+    const uint32_t bl = blk_of(row_to_stored(ix, l), ol_);
+    uint32_t bk = bl;
     bool need_k = k != 0;
-    if (need_k) { sk = row_to_stored(ix, k - 1); bk = sk / PS_BLK_SYMS; }
+    if (need_k) bk = blk_of(row_to_stored(ix, k - 1), ok_);
     Blk xl, xk;
     load_blk(ix.blocks, bl, xl);
     bool other = need_k && bk != bl;
     if (other) load_blk(ix.blocks, bk, xk);
-    ol = blk_count1(xl, (int)(sl - bl * PS_BLK_SYMS) + 1, c);
+    ol = blk_count1(xl, ol_ + 1, c);
     if (!need_k) ok = 0;
-    else if (other) ok = blk_count1(xk, (int)(sk - bk * PS_BLK_SYMS) + 1, c);
-    else ok = blk_count1(xl, (int)(sk - bk * PS_BLK_SYMS) + 1, c);
+    else if (other) ok = blk_count1(xk, ok_ + 1, c);
+    else ok = blk_count1(xl, ok_ + 1, c);
     ++st.pairs;
     if (need_k && !other) ++st.same;
 }
@@ -177,7 +193,7 @@ PS_HD void wchain_step(const IndexView &ix, WChain &c, int base, uint32_t &w_out
         c.l = l2 + ol;
     }
     if (c.k > c.l || base > 3) { c.k = 0; c.l = ix.seq_len; ++c.bid; }
-    uint32_t w = c.l - c.k + 1;
+    uint32_t w = width32(c.k, c.l);
     w_out = w;
     cw_out = cw_pack(c.bid, !first && w == c.prev_w);
     c.prev_w = w;
@@ -244,7 +260,8 @@ PS_HD int seq_at(const BtMem &m, int j, int len)
 // The stack of one lane.  NARROW (tiers 1-2): 16-byte entries, bump allocation, bucket heads in LDS --
 // one 16-byte global store per push and one 16-byte load per pop.  WIDE (last tier, up to the 2,000,000
 // live entries upstream allows): 32-byte entries with a free list and heads in global memory.
-struct Entry16 { uint32_t k, l, a, b; };
+struct Entry16 { uint32_t k, l, a, b; };   // k, l: low words; bit 32 of each sits in b (bits 3 and 7)
+PS_HD uint32_t e16_hi(bwtint k, bwtint l) { return ((uint32_t)(k >> 32) << 3) | ((uint32_t)(l >> 32) << 7); }
 static const uint32_t PS_NIL16 = 0xFFFFu;
 
 PS_HD bool bm_test(const BtLane &L, int b) { return (((b & 64) ? L.bm1 : L.bm0) >> (b & 63)) & 1ull; }
@@ -317,7 +334,6 @@ PS_HD void bt_push(const BtArgs &a, BtLane &L, BtMem &m, bool want, int i, bwtin
         e.n_mm = (uint8_t)n_mm; e.n_gapo = (uint8_t)n_gapo; e.n_gape = (uint8_t)n_gape;
         e.n_ins = (uint8_t)n_ins; e.n_del = (uint8_t)n_del; e.state = (uint8_t)state;
         e.next = bm_test(L, score) ? m.heads[score] : PS_NIL;
-        e.pad[0] = e.pad[1] = 0;
         store_entry(&pool[idx], e);
         m.heads[score] = idx;
         bm_set(L, score);
@@ -336,10 +352,10 @@ PS_HD void bt_push(const BtArgs &a, BtLane &L, BtMem &m, bool want, int i, bwtin
             const bool nonempty = ((hi ? L.bm1 : L.bm0) & bit) != 0;
             const uint32_t next = nonempty ? (uint32_t)m.heads16[score] : PS_NIL16;
             Entry16 e;
-            e.k = k; e.l = l;
+            e.k = (uint32_t)k; e.l = (uint32_t)l;
             e.a = (uint32_t)i | ((uint32_t)(is_diff ? i : 0) << 8) | ((uint32_t)n_mm << 16) |
                   (((uint32_t)state | ((uint32_t)n_gapo << 2) | ((uint32_t)n_gape << 5)) << 24);
-            e.b = (uint32_t)n_ins | ((uint32_t)n_del << 4) | ((uint32_t)score << 8) | (next << 16);
+            e.b = (uint32_t)n_ins | ((uint32_t)n_del << 4) | ((uint32_t)score << 8) | (next << 16) | e16_hi(k, l);
             store16(reinterpret_cast<Entry16 *>(m.pool) + idx, e);
             m.heads16[score] = (uint16_t)idx;
         }
@@ -375,15 +391,16 @@ PS_HD void push16(BtLane &L, BtMem &m, bool go, bwtint k, bwtint l, uint32_t wa,
     const uint32_t idx = slot16(L, go);
     if (go) {
         const uint32_t next = (L.bm0 & bit) ? (uint32_t)m.heads16[score] : PS_NIL16;
-        Entry16 e; e.k = k; e.l = l; e.a = wa; e.b = wb | (next << 16);
+        Entry16 e; e.k = (uint32_t)k; e.l = (uint32_t)l; e.a = wa; e.b = wb | (next << 16) | e16_hi(k, l);
         store16(reinterpret_cast<Entry16 *>(m.pool) + idx, e);
         m.heads16[score] = (uint16_t)idx;
     }
     L.bm0 |= go ? bit : 0ull;
     L.n_stack += go ? 1 : 0; L.st.pushes += go ? 1u : 0u;
 }
-// up to four children that differ only in their interval (the deletion children): one head read, one head write
-PS_HD void push16_group(BtLane &L, BtMem &m, bool go_all, const bwtint nk[4], const bwtint nl[4], uint32_t wa, uint32_t wb, int score)
+// up to four children that differ only in their interval (the deletion children): one head read, one head write.
+// Child c covers rows [L2[c]+ck[c]+1, L2[c]+cl[c]], non-empty iff ck[c] < cl[c].
+PS_HD void push16_group(BtLane &L, BtMem &m, bool go_all, const IndexView &ix, const uint32_t ck[4], const uint32_t cl[4], uint32_t wa, uint32_t wb, int score)
 {
     const unsigned long long bit = 1ull << score;
     bool any = false;
@@ -391,10 +408,11 @@ PS_HD void push16_group(BtLane &L, BtMem &m, bool go_all, const bwtint nk[4], co
     if (go_all) next = (L.bm0 & bit) ? (uint32_t)m.heads16[score] : PS_NIL16;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const bool go = go_all && nk[j] <= nl[j];
+        const bool go = go_all && ck[j] < cl[j];
         const uint32_t idx = slot16(L, go);
         if (go) {
-            Entry16 e; e.k = nk[j]; e.l = nl[j]; e.a = wa; e.b = wb | (next << 16);
+            const bwtint k = ix.L2[j] + ck[j] + 1, l = ix.L2[j] + cl[j];
+            Entry16 e; e.k = (uint32_t)k; e.l = (uint32_t)l; e.a = wa; e.b = wb | (next << 16) | e16_hi(k, l);
             store16(reinterpret_cast<Entry16 *>(m.pool) + idx, e);
             next = idx;
         }
@@ -427,11 +445,11 @@ PS_HD void bt_pop(const BtArgs &a, BtLane &L, BtMem &m)
         L.free_head = h;
         const uint32_t next = e.b >> 16;
         if (next == PS_NIL16) bm_clr(L, b); else m.heads16[b] = (uint16_t)next;
-        L.k = e.k; L.l = e.l;
+        L.k = (bwtint)e.k | ((bwtint)((e.b >> 3) & 1u) << 32); L.l = (bwtint)e.l | ((bwtint)((e.b >> 7) & 1u) << 32);
         L.i = (int)(e.a & 0xff); L.ldp = (int)((e.a >> 8) & 0xff); L.n_mm = (int)((e.a >> 16) & 0xff);
         const uint32_t g = e.a >> 24;
         L.state = (int)(g & 3); L.n_gapo = (int)((g >> 2) & 7); L.n_gape = (int)(g >> 5);
-        L.n_ins = (int)(e.b & 15); L.n_del = (int)((e.b >> 4) & 15);
+        L.n_ins = (int)(e.b & 7); L.n_del = (int)((e.b >> 4) & 7);
         L.score = (int)((e.b >> 8) & 0xff);
         // units are not stored: profile mode has units == score, stock counts every edit as one unit
         L.units = a.md.profile ? L.score : L.n_mm + L.n_gapo + (a.md.mode_gape ? L.n_gape : 0);
@@ -467,14 +485,15 @@ PS_COLD void bt_hit(const BtArgs &a, BtLane &L, BtMem &m)
     if (!do_add) return;
     // shadow: discount this hit's occurrences from the width bounds left of the last difference
     {
-        uint32_t x = L.l - L.k + 1, j = 0, prev = 0;
+        const uint32_t shadow = a.ix.seq_len > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)a.ix.seq_len;   // marks stay above every real width
+        uint32_t x = (uint32_t)(L.l - L.k + 1), j = 0, prev = 0;
         int lim = L.ldp;
         for (int i = 0; i < lim; ++i) {
             size_t off = (size_t)i * a.n_reads + L.r;
             uint32_t w = a.w[off];
             int bid = m.cw[i] & 0x7f;
             if (w > x) { w -= x; a.w[off] = w; }
-            else if (w == x) { bid = 1; w = a.ix.seq_len - (++j); a.w[off] = w; }
+            else if (w == x) { bid = 1; w = shadow - (++j); a.w[off] = w; }
             m.cw[i] = cw_pack(bid, i > 0 && w == prev);
             prev = w;
         }
@@ -487,7 +506,8 @@ PS_COLD void bt_hit(const BtArgs &a, BtLane &L, BtMem &m)
     AlnRec rec;
     rec.k = L.k; rec.l = L.l; rec.score = (uint16_t)L.score; rec.units = (uint16_t)L.units;
     rec.n_mm = (uint8_t)L.n_mm; rec.n_gapo = (uint8_t)L.n_gapo; rec.n_gape = (uint8_t)L.n_gape;
-    rec.n_ins = (uint8_t)L.n_ins; rec.n_del = (uint8_t)L.n_del; rec.pad[0] = rec.pad[1] = rec.pad[2] = 0;
+    rec.n_ins = (uint8_t)L.n_ins; rec.n_del = (uint8_t)L.n_del;
+    for (int j = 0; j < 7; ++j) rec.pad[j] = 0;
     out[L.n_aln++] = rec;
 }
 
@@ -567,16 +587,15 @@ PS_HD void bt_iter(const BtArgs &a, BtLane &L, BtMem &m, int fetch_r, bool serve
     // ---- the memory step, shared by both search modes: Occ(k-1,.) and Occ(l,.) -> the four child intervals ----
     uint32_t ck[4], cl[4];
     occ_pair4(a.ix, L.k, L.l, ck, cl, L.st);
-    bwtint nk[4], nl[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) { nk[c] = a.ix.L2[c] + ck[c] + 1; nl[c] = a.ix.L2[c] + cl[c]; }
+    // child interval of text symbol c: rows [L2[c]+ck[c]+1, L2[c]+cl[c]], non-empty iff ck[c] < cl[c]
     if (L.mode == M_EXACT) {          // no difference left: extend exactly, one base per iteration
         const int c = seq_at(m, L.i - 1, len);
         ++L.st.exact;
         if (c > 3) { L.mode = M_POP; return; }
-        const bwtint k2 = sel4(nk, c), l2 = sel4(nl, c);
-        if (k2 > l2) { L.mode = M_POP; return; }
-        L.k = k2; L.l = l2; --L.i;
+        const uint32_t ok = sel4(ck, c), ol = sel4(cl, c);
+        if (ok >= ol) { L.mode = M_POP; return; }
+        const bwtint base = L2_of(a.ix, c);
+        L.k = base + ok + 1; L.l = base + ol; --L.i;
         if (L.i == 0) L.mode = M_HIT;
         return;
     }
@@ -630,7 +649,7 @@ PS_HD void bt_iter(const BtArgs &a, BtLane &L, BtMem &m, int fetch_r, bool serve
                 const bool ext = from_d && e_ge < md.max_gape && ((e_ge + e_go) * md.u_tight < L.max_units || occ < (bwtint)md.max_del_occ);
                 const int sc = e_sc + (open ? md.s_gapo_del : md.s_gape), un = e_un + (open ? md.u_gapo_del : md.u_gape);
                 const bool go = gap_ok && (open || ext) && un <= L.max_units;
-                push16_group(L, m, go, nk, nl, e16_a(i + 1, true, e_mm, ST_D, e_go + (open ? 1 : 0), e_ge + (open ? 0 : 1)), e16_b(e_ni, e_nd + 1, sc), sc);
+                push16_group(L, m, go, a.ix, ck, cl, e16_a(i + 1, true, e_mm, ST_D, e_go + (open ? 1 : 0), e_ge + (open ? 0 : 1)), e16_b(e_ni, e_nd + 1, sc), sc);
             }
             L.mode = M_POP;
             const bool do_mm = allow_diff && allow_M;
@@ -638,8 +657,9 @@ PS_HD void bt_iter(const BtArgs &a, BtLane &L, BtMem &m, int fetch_r, bool serve
             for (int j = 1; j <= 4; ++j) {
                 const int c = (s + j) & 3;
                 const bool is_mm = (j != 4 || s > 3);
-                const bwtint k2 = sel4(nk, c), l2 = sel4(nl, c);
-                const bool ok = k2 <= l2;
+                const uint32_t okc = sel4(ck, c), olc = sel4(cl, c);
+                const bwtint base = L2_of(a.ix, c), k2 = base + okc + 1, l2 = base + olc;
+                const bool ok = okc < olc;
                 if (j < 4 || s > 3) {       // mismatch children (the fourth only for an N in the read)
                     const int sc = e_sc + cost_of(md.s_mm_pk, s, c), un = e_un + cost_of(md.u_mm_pk, s, c);
                     push16(L, m, do_mm && ok && is_mm && un <= L.max_units, k2, l2, e16_a(i, true, e_mm + 1, ST_M, e_go, e_ge), e16_b(e_ni, e_nd, sc), sc);
@@ -656,7 +676,7 @@ PS_HD void bt_iter(const BtArgs &a, BtLane &L, BtMem &m, int fetch_r, bool serve
                     bt_push<WIDE>(a, L, m, true, i, ek, el, e_mm, e_go + 1, e_ge, e_ni + 1, e_nd, ST_I, true, e_sc + md.s_gapo_ins, e_un + md.u_gapo_ins);
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        bt_push<WIDE>(a, L, m, nk[j] <= nl[j], i + 1, nk[j], nl[j], e_mm, e_go + 1, e_ge, e_ni, e_nd + 1, ST_D, true, e_sc + md.s_gapo_del, e_un + md.u_gapo_del);
+                        bt_push<WIDE>(a, L, m, ck[j] < cl[j], i + 1, a.ix.L2[j] + ck[j] + 1, a.ix.L2[j] + cl[j], e_mm, e_go + 1, e_ge, e_ni, e_nd + 1, ST_D, true, e_sc + md.s_gapo_del, e_un + md.u_gapo_del);
                 }
             } else if (e_st == ST_I) {
                 if (e_ge < md.max_gape)
@@ -665,7 +685,7 @@ PS_HD void bt_iter(const BtArgs &a, BtLane &L, BtMem &m, int fetch_r, bool serve
                 if (e_ge < md.max_gape && ((e_ge + e_go) * md.u_tight < L.max_units || occ < (bwtint)md.max_del_occ)) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        bt_push<WIDE>(a, L, m, nk[j] <= nl[j], i + 1, nk[j], nl[j], e_mm, e_go, e_ge + 1, e_ni, e_nd + 1, ST_D, true, e_sc + md.s_gape, e_un + md.u_gape);
+                        bt_push<WIDE>(a, L, m, ck[j] < cl[j], i + 1, a.ix.L2[j] + ck[j] + 1, a.ix.L2[j] + cl[j], e_mm, e_go, e_ge + 1, e_ni, e_nd + 1, ST_D, true, e_sc + md.s_gape, e_un + md.u_gape);
                 }
             }
         }
@@ -675,29 +695,37 @@ PS_HD void bt_iter(const BtArgs &a, BtLane &L, BtMem &m, int fetch_r, bool serve
             for (int j = 1; j <= 4; ++j) {
                 const int c = (s + j) & 3;
                 const bool is_mm = (j != 4 || s > 3);
-                const bwtint k2 = sel4(nk, c), l2 = sel4(nl, c);
-                const bool ok = k2 <= l2;
+                const uint32_t okc = sel4(ck, c), olc = sel4(cl, c);
+                const bwtint base = L2_of(a.ix, c), k2 = base + okc + 1, l2 = base + olc;
+                const bool ok = okc < olc;
                 bt_push<WIDE>(a, L, m, ok && is_mm, i, k2, l2, e_mm + 1, e_go, e_ge, e_ni, e_nd, ST_M, true, e_sc + cost_of(md.s_mm_pk, s, c), e_un + cost_of(md.u_mm_pk, s, c));
                 if (ok && !is_mm) { // the match child has the parent's score and is pushed last: it is the next pop
                     L.k = k2; L.l = l2; L.i = i; L.state = ST_M; L.ldp = 0; L.have_cur = true;
                 }
             }
         } else if (s < 4) {
-            const bwtint k2 = sel4(nk, s), l2 = sel4(nl, s);
-            if (k2 <= l2) { L.k = k2; L.l = l2; L.i = i; L.state = ST_M; L.ldp = 0; L.have_cur = true; }
+            const uint32_t okc = sel4(ck, s), olc = sel4(cl, s);
+            const bwtint base = L2_of(a.ix, s);
+            if (okc < olc) { L.k = base + okc + 1; L.l = base + olc; L.i = i; L.state = ST_M; L.ldp = 0; L.have_cur = true; }
         }
     }
 }
 
 // ------------------------------------------------------- SA row -> text ---
+// sampled suffix array entry t (row t*sa_intv); entry 0 is the row of the empty suffix and stands for -1
+PS_HD bwtint sa_sample(const IndexView &ix, bwtint t)
+{
+    if (t == 0) return ~(bwtint)0;
+    return (bwtint)ix.sa[t] | ((bwtint)((ix.sa_hi[t >> 5] >> (t & 31)) & 1u) << 32);
+}
 // Walk LF until a sampled row (upstream bwt_sa): one block load per step.
 PS_HD bool sa_walk_step(const IndexView &ix, bwtint &row, uint32_t &steps, LaneStats &st)
 {
     if ((row & (bwtint)(ix.sa_intv - 1)) == 0) return false;
     ++steps; ++st.lf;
     if (row == ix.primary) { row = 0; return true; }
-    bwtint s = row_to_stored(ix, row), b = s / PS_BLK_SYMS;
-    int pos = (int)(s - b * PS_BLK_SYMS);
+    int pos = 0;
+    const uint32_t b = blk_of(row_to_stored(ix, row), pos);
     Blk x;
     load_blk(ix.blocks, b, x);
     int c = blk_sym(x, pos);

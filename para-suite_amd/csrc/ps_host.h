@@ -59,12 +59,13 @@ struct Rng48 {
 
 struct Index {
     RefSeq ref;
-    DevBuf<OccBlock> blocks; DevBuf<bwtint> sa; DevBuf<uint8_t> pac;
+    DevBuf<OccBlock> blocks; DevBuf<uint32_t> sa; DevBuf<uint8_t> pac;   // sa: n_sa low words, then the bit-32 plane
     IndexView view;
     double build_ms = 0;
     int sa_rounds = 0;
     void refresh_view();
-    size_t device_bytes() const { return blocks.n * sizeof(OccBlock) + sa.n * sizeof(bwtint) + pac.n; }
+    static size_t sa_words(size_t n_sa) { return n_sa + (n_sa + 31) / 32; }
+    size_t device_bytes() const { return blocks.n * sizeof(OccBlock) + sa.n * sizeof(uint32_t) + pac.n; }
 };
 void index_build(const char *fa, Index &ix, hipStream_t s);        // GPU suffix sorting (ps_index.hip)
 void index_save(const Index &ix, const std::string &prefix);

@@ -122,7 +122,18 @@ void Rng48::jump(uint64_t t)
 }
 
 // ------------------------------------------------------ GPU suffix sorting --
+// Suffix array of T$ (T = forward + reverse-complement text, n = 2*l_pac symbols, up to 2^33 rows) by prefix
+// doubling that only ever re-sorts what is still tied (Larsson-Sadakane style), built from hipcub radix sorts:
+//   round 0   the suffixes are split by their first symbol (four chunks, each < 2^32 suffixes); a chunk is
+//             sorted by the 27 symbols that follow (one 63-bit base-5 key), so all suffixes are ordered by
+//             their first 28 symbols and get the rank of their group's first row
+//   round j   only suffixes in groups of two or more remain; they are ordered inside their group by the rank
+//             of the suffix h symbols further on (two stable sorts: by that rank, then by group), groups split,
+//             singletons drop out, h doubles
+// SA and inverse SA (8 bytes per row each) stay in HBM: 6.27e9 rows (hg19) need ~100 GB for them, ~50 GB for
+// the chunk being sorted and whatever is still tied -- well inside one MI355X's 288 GB; there is no host sorter.
 typedef unsigned long long u64;
+static const int GRID = 256 * 8, BLK = 256;
 
 __global__ void k_expand_text(const uint8_t *pac, uint8_t *T, u64 l_pac)
 {
@@ -132,45 +143,89 @@ __global__ void k_expand_text(const uint8_t *pac, uint8_t *T, u64 l_pac)
         T[2 * l_pac - 1 - i] = (uint8_t)(3 - b);     // reverse complement strand appended
     }
 }
-// first sort key: 27 base-5 digits (symbol+1, 0 beyond the text) -> suffixes that reach '$' order first
-__global__ void k_init_keys(const uint8_t *T, u64 n, u64 *key, bwtint *sa)
+__global__ void k_count_syms(const uint8_t *T, u64 n, u64 *cnt)
 {
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += (u64)gridDim.x * blockDim.x) {
+    u64 c[4] = {0, 0, 0, 0};
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        const int s = T[i];
+        c[0] += s == 0; c[1] += s == 1; c[2] += s == 2; c[3] += s == 3;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        u64 v = c[j];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(cnt + j, v);
+    }
+}
+// positions of the suffixes that start with symbol c (order does not matter: they are sorted next)
+__global__ void k_collect(const uint8_t *T, u64 n, int c, u64 *out, u64 *counter)
+{
+    const int lane = threadIdx.x & 63;
+    const u64 lane_lt = (1ull << lane) - 1ull;
+    for (u64 base = ((u64)blockIdx.x * blockDim.x + threadIdx.x) - lane; base < n; base += (u64)gridDim.x * blockDim.x) {
+        const u64 i = base + lane;
+        const bool f = i < n && T[i] == c;
+        const u64 mask = __ballot(f);
+        if (mask == 0) continue;
+        u64 at = 0;
+        if (lane == 0) at = atomicAdd(counter, (u64)__popcll(mask));
+        at = (u64)__shfl((long long)at, 0, 64);
+        if (f) out[at + __popcll(mask & lane_lt)] = i;
+    }
+}
+// sort key of a suffix inside its chunk: the 27 symbols after the first as base-5 digits (symbol+1, 0 beyond the
+// text), so a suffix that runs into '$' orders before every longer one
+__global__ void k_chunk_keys(const uint8_t *T, u64 n, const u64 *pos, u64 m, u64 *key)
+{
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (u64)gridDim.x * blockDim.x) {
+        const u64 p = pos[i] + 1;
         u64 k = 0;
 #pragma unroll
-        for (int j = 0; j < 27; ++j) k = k * 5 + (i + j < n ? (u64)T[i + j] + 1 : 0);
-        key[i] = k; sa[i] = (bwtint)i;
+        for (int j = 0; j < 27; ++j) k = k * 5 + (p + j < n ? (u64)T[p + j] + 1 : 0);
+        key[i] = k;
     }
 }
-__global__ void k_group_flags(const u64 *key, u64 N, bwtint *gstart, unsigned long long *n_groups)
+// head[i] = first element of a group of equal keys (optionally inside equal outer groups); val[i] = head ? at[i] : 0
+__global__ void k_heads(const u64 *key, const u64 *outer, u64 m, u64 first_row, const u64 *rows, uint32_t *head, u64 *val)
 {
-    unsigned long long local = 0;
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (u64)gridDim.x * blockDim.x) {
-        bool head = i == 0 || key[i] != key[i - 1];
-        gstart[i] = head ? (bwtint)i : 0;
-        local += head;
-    }
-    for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o, 64);
-    if ((threadIdx.x & 63) == 0 && local) atomicAdd(n_groups, local);
-}
-__global__ void k_scatter_rank(const bwtint *sa, const bwtint *gstart, u64 N, bwtint *rank)
-{
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (u64)gridDim.x * blockDim.x) rank[sa[i]] = gstart[i];
-}
-__global__ void k_double_keys(const bwtint *sa, const bwtint *rank, u64 N, u64 h, u64 *key)
-{
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (u64)gridDim.x * blockDim.x) {
-        u64 p = sa[i];
-        key[i] = ((u64)rank[p] << 32) | (p + h < N ? (u64)rank[p + h] : 0ull);
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (u64)gridDim.x * blockDim.x) {
+        const bool h = i == 0 || key[i] != key[i - 1] || (outer && outer[i] != outer[i - 1]);
+        head[i] = h ? 1u : 0u;
+        val[i] = h ? (rows ? rows[i] : first_row + i) : 0ull;
     }
 }
-__global__ void k_find_primary(const bwtint *sa, u64 N, bwtint *primary)
+// after the max-scan val[i] is the rank (row of the group's first element): publish SA and inverse SA, flag ties
+__global__ void k_publish(const u64 *pos, const u64 *rank, const uint32_t *head, u64 m, u64 first_row, const u64 *rows,
+                          u64 *SA, u64 *ISA, uint32_t *tied)
 {
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (u64)gridDim.x * blockDim.x)
-        if (sa[i] == 0) *primary = (bwtint)i;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (u64)gridDim.x * blockDim.x) {
+        const u64 p = pos[i];
+        SA[rows ? rows[i] : first_row + i] = p;
+        ISA[p] = rank[i];
+        const bool single = head[i] && (i + 1 == m || head[i + 1]);
+        tied[i] = single ? 0u : 1u;
+    }
+}
+__global__ void k_compact_tied(const uint32_t *tied, const uint32_t *off, u64 m, const u64 *pos, const u64 *rank, u64 first_row,
+                               const u64 *rows, u64 *o_pos, u64 *o_grp, u64 *o_row)
+{
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (u64)gridDim.x * blockDim.x)
+        if (tied[i]) { const uint32_t q = off[i]; o_pos[q] = pos[i]; o_grp[q] = rank[i]; o_row[q] = rows ? rows[i] : first_row + i; }
+}
+__global__ void k_next_keys(const u64 *pos, const u64 *ISA, u64 m, u64 h, u64 N, u64 *key, uint32_t *idx)
+{
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (u64)gridDim.x * blockDim.x) {
+        const u64 p = pos[i] + h;
+        key[i] = p < N ? ISA[p] : 0ull;
+        idx[i] = (uint32_t)i;
+    }
+}
+__global__ void k_gather64(const u64 *src, const uint32_t *idx, u64 m, u64 *dst)
+{
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (u64)gridDim.x * blockDim.x) dst[i] = src[idx[i]];
 }
 // stored BWT symbol j (the '$' row skipped) = T[SA[row]-1]
-__global__ void k_bwt_syms(const bwtint *sa, const uint8_t *T, u64 n, bwtint primary, uint8_t *B)
+__global__ void k_bwt_syms(const u64 *sa, const uint8_t *T, u64 n, u64 primary, uint8_t *B)
 {
     for (u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (u64)gridDim.x * blockDim.x) {
         u64 row = j + (j >= primary ? 1 : 0);
@@ -201,106 +256,209 @@ __global__ void k_pack_blocks(const uint8_t *B, u64 n, uint32_t n_blocks, const 
         blocks[b] = blk;
     }
 }
-__global__ void k_sample_sa(const bwtint *sa, uint32_t n_sa, int intv, bwtint *out)
+// sampled SA: low words, then one word of bit-32 flags per 32 samples
+__global__ void k_sample_sa(const u64 *sa, uint32_t n_sa, int intv, uint32_t *lo, uint32_t *hi)
 {
-    for (u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x; t < n_sa; t += (u64)gridDim.x * blockDim.x)
-        out[t] = t == 0 ? 0xFFFFFFFFu : sa[t * (u64)intv];
+    const uint32_t n_words = (n_sa + 31) / 32;
+    for (u64 wd = (u64)blockIdx.x * blockDim.x + threadIdx.x; wd < n_words; wd += (u64)gridDim.x * blockDim.x) {
+        uint32_t bits = 0;
+        for (int j = 0; j < 32; ++j) {
+            const u64 t = wd * 32 + j;
+            if (t >= n_sa) break;
+            const u64 v = t == 0 ? ~0ull : sa[t * (u64)intv];
+            lo[t] = (uint32_t)v;
+            bits |= (uint32_t)((v >> 32) & 1ull) << j;
+        }
+        hi[wd] = bits;
+    }
 }
 
 void Index::refresh_view()
 {
-    view.blocks = blocks.p; view.sa = sa.p; view.pac = pac.p;
+    view.blocks = blocks.p; view.sa = sa.p; view.sa_hi = sa.p + view.n_sa; view.pac = pac.p;
     view.l_pac = (bwtint)ref.l_pac; view.seq_len = (bwtint)(2 * ref.l_pac);
-    view.n_blocks = (uint32_t)blocks.n; view.n_sa = (uint32_t)sa.n; view.sa_intv = 32;
+    view.n_blocks = (uint32_t)blocks.n; view.sa_intv = 32;
 }
 
-static const int GRID = 256 * 8, BLK = 256;
+namespace {
+struct Sorter {          // hipcub calls with one grow-only temporary buffer
+    DevBuf<uint8_t> tmp; hipStream_t s;
+    void need(size_t b) { if (b > tmp.n) tmp.alloc(b + b / 8 + 256); }
+    template <class V> void pairs(const u64 *kin, u64 *kout, const V *vin, V *vout, size_t m, int end_bit)
+    {
+        size_t b = 0;
+        PS_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, b, kin, kout, vin, vout, m, 0, end_bit, s));
+        need(b); b = tmp.n;
+        PS_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.p, b, kin, kout, vin, vout, m, 0, end_bit, s));
+    }
+    void max_scan(u64 *v, size_t m)
+    {
+        size_t b = 0;
+        PS_HIP(hipcub::DeviceScan::InclusiveScan(nullptr, b, v, v, hipcub::Max(), m, s));
+        need(b); b = tmp.n;
+        PS_HIP(hipcub::DeviceScan::InclusiveScan(tmp.p, b, v, v, hipcub::Max(), m, s));
+    }
+    void ex_sum(const uint32_t *in, uint32_t *out, size_t m)
+    {
+        size_t b = 0;
+        PS_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, b, in, out, m, s));
+        need(b); b = tmp.n;
+        PS_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, b, in, out, m, s));
+    }
+};
+struct Tied { DevBuf<u64> pos, grp, row; size_t m = 0; };   // suffixes still in groups of two or more, in row order
+
+// ranks are in `rank` (after the max-scan), heads in `head`: publish, then append the tied ones to `out`
+void publish_and_compact(Sorter &so, const u64 *pos, u64 *rank, const uint32_t *head, size_t m, u64 first_row, const u64 *rows,
+                         u64 *SA, u64 *ISA, Tied &out)
+{
+    hipStream_t s = so.s;
+    DevBuf<uint32_t> tied, off; tied.alloc(m); off.alloc(m);
+    hipLaunchKernelGGL(k_publish, dim3(GRID), dim3(BLK), 0, s, pos, rank, head, (u64)m, first_row, rows, SA, ISA, tied.p);
+    so.ex_sum(tied.p, off.p, m);
+    uint32_t last_off = 0, last_flag = 0;
+    PS_HIP(hipMemcpyAsync(&last_off, off.p + (m - 1), 4, hipMemcpyDeviceToHost, s));
+    PS_HIP(hipMemcpyAsync(&last_flag, tied.p + (m - 1), 4, hipMemcpyDeviceToHost, s));
+    PS_HIP(hipStreamSynchronize(s));
+    out.m = (size_t)last_off + last_flag;
+    if (out.m) {
+        out.pos.alloc(out.m); out.grp.alloc(out.m); out.row.alloc(out.m);
+        hipLaunchKernelGGL(k_compact_tied, dim3(GRID), dim3(BLK), 0, s, tied.p, off.p, (u64)m, pos, rank, first_row, rows, out.pos.p, out.grp.p, out.row.p);
+    }
+    PS_HIP(hipStreamSynchronize(s));
+}
+}  // namespace
 
 void index_build(const char *fa, Index &ix, hipStream_t s)
 {
     auto t0 = std::chrono::steady_clock::now();
     load_fasta(fa, ix.ref);
     const u64 l_pac = (u64)ix.ref.l_pac, n = 2 * l_pac, N = n + 1;
-    if (N >= 0xFFFFFFFFull) throw Error("reference too large for the 32-bit index of this build (2*l_pac must be < 2^32-1)");
+    if (N >= PS_MAX_ROWS) throw Error("reference too large: forward + reverse strand must stay below 2^33 rows (4.29 Gbp)");
     ix.pac.alloc(ix.ref.pac.size());
     ix.pac.upload(ix.ref.pac.data(), ix.ref.pac.size(), s);
-    DevBuf<uint8_t> T; T.alloc(n + 32);
+    DevBuf<uint8_t> T; T.alloc(n + 64);
     hipLaunchKernelGGL(k_expand_text, dim3(GRID), dim3(BLK), 0, s, ix.pac.p, T.p, l_pac);
-    DevBuf<u64> keyA, keyB; DevBuf<bwtint> saA, saB, rank, gstart; DevBuf<unsigned long long> cnt;
-    keyA.alloc(N); keyB.alloc(N); saA.alloc(N); saB.alloc(N); rank.alloc(N); gstart.alloc(N); cnt.alloc(1);
-    hipLaunchKernelGGL(k_init_keys, dim3(GRID), dim3(BLK), 0, s, T.p, n, keyA.p, saA.p);
-    size_t tmp_sort = 0, tmp_scan = 0;
-    PS_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_sort, keyA.p, keyB.p, saA.p, saB.p, (size_t)N, 0, 64, s));
-    PS_HIP(hipcub::DeviceScan::InclusiveScan(nullptr, tmp_scan, gstart.p, gstart.p, hipcub::Max(), (size_t)N, s));
-    DevBuf<uint8_t> tmp; tmp.alloc(tmp_sort > tmp_scan ? tmp_sort : tmp_scan);
-    size_t tb = tmp.n;
-    PS_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, keyA.p, keyB.p, saA.p, saB.p, (size_t)N, 0, 63, s));
-    ix.sa_rounds = 0;
-    for (u64 h = 27;; h *= 2) {
-        // sorted keys in keyB, suffix order in saB
-        cnt.zero(s);
-        hipLaunchKernelGGL(k_group_flags, dim3(GRID), dim3(BLK), 0, s, keyB.p, N, gstart.p, cnt.p);
-        unsigned long long groups = 0;
-        cnt.download(&groups, 1, s);
-        PS_HIP(hipStreamSynchronize(s));
-        ++ix.sa_rounds;
-        if (groups == N) break;
-        if (h > N) throw Error("suffix sorting did not converge");
-        tb = tmp.n;
-        PS_HIP(hipcub::DeviceScan::InclusiveScan(tmp.p, tb, gstart.p, gstart.p, hipcub::Max(), (size_t)N, s));
-        hipLaunchKernelGGL(k_scatter_rank, dim3(GRID), dim3(BLK), 0, s, saB.p, gstart.p, N, rank.p);
-        hipLaunchKernelGGL(k_double_keys, dim3(GRID), dim3(BLK), 0, s, saB.p, rank.p, N, h, keyA.p);
-        PS_HIP(hipMemcpyAsync(saA.p, saB.p, N * sizeof(bwtint), hipMemcpyDeviceToDevice, s));
-        tb = tmp.n;
-        PS_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, keyA.p, keyB.p, saA.p, saB.p, (size_t)N, 0, 64, s));
-    }
-    keyA.release(); keyB.release(); rank.release(); gstart.release(); saA.release();
-    // BWT, Occ blocks, sampled SA
-    DevBuf<bwtint> dprim; dprim.alloc(1);
-    hipLaunchKernelGGL(k_find_primary, dim3(GRID), dim3(BLK), 0, s, saB.p, N, dprim.p);
-    bwtint primary = 0;
-    dprim.download(&primary, 1, s);
+    DevBuf<u64> dcnt; dcnt.alloc(5); dcnt.zero(s);
+    hipLaunchKernelGGL(k_count_syms, dim3(GRID), dim3(BLK), 0, s, T.p, n, dcnt.p);
+    u64 cnt[5] = {0, 0, 0, 0, 0};
+    dcnt.download(cnt, 5, s);
     PS_HIP(hipStreamSynchronize(s));
+    for (int c = 0; c < 4; ++c)
+        if (cnt[c] >= 0xFFFFFF00ull) throw Error("reference too skewed: one base occurs 2^32 times or more");
+    DevBuf<u64> SA, ISA; SA.alloc(N); ISA.alloc(N);
+    Sorter so; so.s = s;
+    // ---- round 0: chunk by first symbol, order by the next 27 ----
+    {
+        const u64 nn = n;                                  // row 0: the empty suffix
+        PS_HIP(hipMemcpyAsync(SA.p, &nn, 8, hipMemcpyHostToDevice, s));
+        const u64 zero = 0;
+        PS_HIP(hipMemcpyAsync(ISA.p + n, &zero, 8, hipMemcpyHostToDevice, s));
+        PS_HIP(hipStreamSynchronize(s));
+    }
+    std::vector<Tied> parts(4);
+    u64 first_row = 1;
+    for (int c = 0; c < 4; ++c) {
+        const size_t m = (size_t)cnt[c];
+        if (m == 0) continue;
+        DevBuf<u64> posA, posB, keyA, keyB; posA.alloc(m); posB.alloc(m); keyA.alloc(m); keyB.alloc(m);
+        dcnt.zero(s);
+        hipLaunchKernelGGL(k_collect, dim3(GRID), dim3(BLK), 0, s, T.p, n, c, posA.p, dcnt.p + 4);
+        hipLaunchKernelGGL(k_chunk_keys, dim3(GRID), dim3(BLK), 0, s, T.p, n, posA.p, (u64)m, keyA.p);
+        so.pairs<u64>(keyA.p, keyB.p, posA.p, posB.p, m, 63);
+        posA.release();
+        DevBuf<uint32_t> head; head.alloc(m);
+        u64 *rank = keyA.p;                                // reuse: the unsorted keys are no longer needed
+        hipLaunchKernelGGL(k_heads, dim3(GRID), dim3(BLK), 0, s, keyB.p, (const u64 *)nullptr, (u64)m, first_row, (const u64 *)nullptr, head.p, rank);
+        so.max_scan(rank, m);
+        publish_and_compact(so, posB.p, rank, head.p, m, first_row, nullptr, SA.p, ISA.p, parts[c]);
+        first_row += m;
+    }
+    Tied cur;
+    for (int c = 0; c < 4; ++c) cur.m += parts[c].m;
+    if (cur.m) {
+        cur.pos.alloc(cur.m); cur.grp.alloc(cur.m); cur.row.alloc(cur.m);
+        size_t at = 0;
+        for (int c = 0; c < 4; ++c) {
+            if (!parts[c].m) continue;
+            PS_HIP(hipMemcpyAsync(cur.pos.p + at, parts[c].pos.p, parts[c].m * 8, hipMemcpyDeviceToDevice, s));
+            PS_HIP(hipMemcpyAsync(cur.grp.p + at, parts[c].grp.p, parts[c].m * 8, hipMemcpyDeviceToDevice, s));
+            PS_HIP(hipMemcpyAsync(cur.row.p + at, parts[c].row.p, parts[c].m * 8, hipMemcpyDeviceToDevice, s));
+            at += parts[c].m;
+        }
+        PS_HIP(hipStreamSynchronize(s));
+    }
+    parts.clear();
+    ix.sa_rounds = 1;
+    // ---- doubling rounds over what is still tied ----
+    for (u64 h = 28; cur.m; h *= 2) {
+        if (h > 2 * N) throw Error("suffix sorting did not converge");
+        if (cur.m >= 0xFFFFFFFFull) throw Error("reference too repetitive for the 32-bit tie lists of the index builder");
+        const size_t m = cur.m;
+        DevBuf<u64> key, keyS, g1, g1S, pos2; DevBuf<uint32_t> idx0, idx1, idx2, head;
+        key.alloc(m); keyS.alloc(m); idx0.alloc(m); idx1.alloc(m);
+        hipLaunchKernelGGL(k_next_keys, dim3(GRID), dim3(BLK), 0, s, cur.pos.p, ISA.p, (u64)m, h, N, key.p, idx0.p);
+        so.pairs<uint32_t>(key.p, keyS.p, idx0.p, idx1.p, m, 34);
+        g1.alloc(m); g1S.alloc(m); idx2.alloc(m);
+        hipLaunchKernelGGL(k_gather64, dim3(GRID), dim3(BLK), 0, s, cur.grp.p, idx1.p, (u64)m, g1.p);
+        so.pairs<uint32_t>(g1.p, g1S.p, idx1.p, idx2.p, m, 34);     // stable: ties keep the order of the first sort
+        // g1S equals cur.grp (it was already in row order); element i now belongs in row cur.row[i]
+        pos2.alloc(m);
+        hipLaunchKernelGGL(k_gather64, dim3(GRID), dim3(BLK), 0, s, cur.pos.p, idx2.p, (u64)m, pos2.p);
+        hipLaunchKernelGGL(k_gather64, dim3(GRID), dim3(BLK), 0, s, key.p, idx2.p, (u64)m, keyS.p);
+        head.alloc(m);
+        u64 *rank = g1.p;
+        hipLaunchKernelGGL(k_heads, dim3(GRID), dim3(BLK), 0, s, keyS.p, g1S.p, (u64)m, 0ull, cur.row.p, head.p, rank);
+        so.max_scan(rank, m);
+        Tied next;
+        publish_and_compact(so, pos2.p, rank, head.p, m, 0, cur.row.p, SA.p, ISA.p, next);
+        cur = std::move(next);
+        ++ix.sa_rounds;
+    }
+    u64 primary = 0;
+    PS_HIP(hipMemcpyAsync(&primary, ISA.p, 8, hipMemcpyDeviceToHost, s));   // row of the whole text = where '$' sits in the last column
+    PS_HIP(hipStreamSynchronize(s));
+    ISA.release(); so.tmp.release();
+    // BWT, Occ blocks, sampled SA
     DevBuf<uint8_t> B; B.alloc(n + 1);
-    hipLaunchKernelGGL(k_bwt_syms, dim3(GRID), dim3(BLK), 0, s, saB.p, T.p, n, primary, B.p);
+    hipLaunchKernelGGL(k_bwt_syms, dim3(GRID), dim3(BLK), 0, s, SA.p, T.p, n, primary, B.p);
     const uint32_t n_blocks = (uint32_t)(n / PS_BLK_SYMS + 1);
     DevBuf<uint32_t> c[4], cs[4];
     for (int j = 0; j < 4; ++j) { c[j].alloc(n_blocks); cs[j].alloc(n_blocks); }
     hipLaunchKernelGGL(k_block_counts, dim3(GRID), dim3(BLK), 0, s, B.p, n, n_blocks, c[0].p, c[1].p, c[2].p, c[3].p);
-    size_t tmp2 = 0;
-    PS_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp2, c[0].p, cs[0].p, (size_t)n_blocks, s));
-    if (tmp2 > tmp.n) tmp.alloc(tmp2);
     uint32_t last_c[4], last_s[4];
     for (int j = 0; j < 4; ++j) {
-        tb = tmp.n;
-        PS_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, c[j].p, cs[j].p, (size_t)n_blocks, s));
+        so.ex_sum(c[j].p, cs[j].p, n_blocks);
         PS_HIP(hipMemcpyAsync(&last_c[j], c[j].p + (n_blocks - 1), 4, hipMemcpyDeviceToHost, s));
         PS_HIP(hipMemcpyAsync(&last_s[j], cs[j].p + (n_blocks - 1), 4, hipMemcpyDeviceToHost, s));
     }
     ix.blocks.alloc(n_blocks);
     hipLaunchKernelGGL(k_pack_blocks, dim3(GRID), dim3(BLK), 0, s, B.p, n, n_blocks, cs[0].p, cs[1].p, cs[2].p, cs[3].p, ix.blocks.p);
     const uint32_t n_sa = (uint32_t)((n + 32) / 32);
-    ix.sa.alloc(n_sa);
-    hipLaunchKernelGGL(k_sample_sa, dim3(GRID), dim3(BLK), 0, s, saB.p, n_sa, 32, ix.sa.p);
+    ix.sa.alloc(Index::sa_words(n_sa));
+    hipLaunchKernelGGL(k_sample_sa, dim3(GRID), dim3(BLK), 0, s, SA.p, n_sa, 32, ix.sa.p, ix.sa.p + n_sa);
     PS_HIP(hipStreamSynchronize(s));
     ix.view.primary = primary;
     ix.view.L2[0] = 0;
     for (int j = 0; j < 4; ++j) ix.view.L2[j + 1] = ix.view.L2[j] + last_c[j] + last_s[j];
+    ix.view.n_sa = n_sa;
     ix.refresh_view();
     if (ix.view.L2[4] != (bwtint)n) throw Error("index build: symbol counts do not add up");
+    for (int j = 0; j < 4; ++j)
+        if (ix.view.L2[j + 1] - ix.view.L2[j] != cnt[j]) throw Error("index build: BWT symbol counts differ from the text's");
     ix.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
 // ------------------------------------------------------------- files ---------
 // <ref>.bwt (header + Occ blocks), <ref>.sa, <ref>.pac, <ref>.ann (contigs + holes), this project's formats.
-static const char MAGIC_BWT[8] = {'P', 'S', 'B', 'W', 'T', '0', '1', 0};
+static const char MAGIC_BWT[8] = {'P', 'S', 'B', 'W', 'T', '0', '2', 0};
 
 std::string index_meta_serialize(const Index &ix)
 {
     std::ostringstream o;
-    o << "PSANN01\n" << ix.ref.l_pac << ' ' << ix.ref.contigs.size() << ' ' << ix.ref.holes.size() << '\n';
+    o << "PSANN02\n" << ix.ref.l_pac << ' ' << ix.ref.contigs.size() << ' ' << ix.ref.holes.size() << '\n';
     o << ix.view.seq_len << ' ' << ix.view.primary << ' ' << ix.view.L2[0] << ' ' << ix.view.L2[1] << ' ' << ix.view.L2[2] << ' '
-      << ix.view.L2[3] << ' ' << ix.view.L2[4] << ' ' << ix.blocks.n << ' ' << ix.sa.n << ' ' << ix.pac.n << '\n';
+      << ix.view.L2[3] << ' ' << ix.view.L2[4] << ' ' << ix.blocks.n << ' ' << ix.view.n_sa << ' ' << ix.pac.n << '\n';
     for (const Contig &c : ix.ref.contigs) o << c.name << '\t' << c.offset << '\t' << c.len << '\t' << c.n_ambs << '\t' << c.anno << '\n';
     for (const Hole &h : ix.ref.holes) o << h.offset << ' ' << h.len << ' ' << (int)(unsigned char)h.amb << '\n';
     return o.str();
@@ -309,7 +467,7 @@ void index_meta_deserialize(const std::string &blob, Index &ix)
 {
     std::istringstream in(blob);
     std::string magic; std::getline(in, magic);
-    if (magic != "PSANN01") throw Error("bad index metadata");
+    if (magic != "PSANN02") throw Error("bad index metadata");
     size_t nc, nh, nb, ns, np; uint64_t v[7];
     in >> ix.ref.l_pac >> nc >> nh;
     for (int j = 0; j < 7; ++j) in >> v[j];
@@ -363,7 +521,7 @@ template <class T> static void read_dev(const std::string &path, const char *mag
 void index_save(const Index &ix, const std::string &prefix)
 {
     write_dev(prefix + ".bwt", MAGIC_BWT, ix.blocks);
-    write_dev(prefix + ".sa", "PSSA0001", ix.sa);
+    write_dev(prefix + ".sa", "PSSA0002", ix.sa);
     write_dev(prefix + ".pac", "PSPAC001", ix.pac);
     std::ofstream a(prefix + ".ann", std::ios::binary);
     a << index_meta_serialize(ix);
@@ -377,7 +535,7 @@ void index_load(const std::string &prefix, Index &ix, hipStream_t s)
     std::stringstream ss; ss << a.rdbuf();
     index_meta_deserialize(ss.str(), ix);
     read_dev(prefix + ".bwt", MAGIC_BWT, ix.blocks, s);
-    read_dev(prefix + ".sa", "PSSA0001", ix.sa, s);
+    read_dev(prefix + ".sa", "PSSA0002", ix.sa, s);
     read_dev(prefix + ".pac", "PSPAC001", ix.pac, s);
     ix.ref.pac.resize(ix.pac.n);
     PS_HIP(hipMemcpy(ix.ref.pac.data(), ix.pac.p, ix.pac.n, hipMemcpyDeviceToHost));

@@ -101,7 +101,12 @@ __global__ void __launch_bounds__(256) k_backtrack(const BtArgs *__restrict__ ap
     bool exhausted = false;
     for (;;) {
         const bool want = L.mode == M_FETCH;
-        if (!WIDE && want) m.pool = pool_private;              // a new read starts on the lane's private stack slice
+        if (!WIDE && want && m.pool != pool_private) {         // read done on a large slot: hand the slot back
+            const unsigned int slot = (unsigned int)((reinterpret_cast<uint8_t *>(m.pool) - a.big_pool) / ((size_t)a.big_cap * sizeof(Entry16)));
+            __threadfence();                                   // this lane's stores to the slot land before the next owner's
+            atomicExch(a.big_busy + slot, 0u);
+            m.pool = pool_private;                             // a new read starts on the lane's private stack slice
+        }
         const unsigned long long wmask = __ballot(want), lmask = __ballot(L.mode != M_EXIT), hmask = __ballot(L.mode == M_HIT);
         if (lmask == 0) break;
         const bool stalled = (wmask | hmask) == lmask;          // nobody can advance without being served
@@ -134,8 +139,14 @@ __global__ void __launch_bounds__(256) k_backtrack(const BtArgs *__restrict__ ap
             while (gmask) {                                    // wave-uniform loop over the lanes that need a larger stack
                 const int src = __ffsll((unsigned long long)gmask) - 1;
                 gmask &= gmask - 1;
-                unsigned int slot = 0;
-                if (lane == src) slot = atomicAdd(a.big_next, 1u);
+                unsigned int slot = a.n_big;
+                if (lane == src) {                             // claim a free slot: rotating start, bounded probing
+                    unsigned int at = atomicAdd(a.big_next, 1u) % a.n_big;
+                    for (int tries = 0; tries < 256; ++tries) {
+                        if (atomicCAS(a.big_busy + at, 0u, 1u) == 0u) { slot = at; break; }
+                        at = at + 1u == a.n_big ? 0u : at + 1u;
+                    }
+                }
                 slot = (unsigned int)__shfl((int)slot, src, 64);
                 const unsigned int n_copy = (unsigned int)__shfl((int)L.bump, src, 64);
                 const unsigned long long from = (unsigned long long)__shfl((long long)reinterpret_cast<unsigned long long>(m.pool), src, 64);
@@ -166,7 +177,7 @@ __global__ void __launch_bounds__(256) k_sa2pos(IndexView ix, const bwtint *rows
             row = rows[item]; steps = 0; have = true;
         }
         if (!sa_walk_step(ix, row, steps, st)) {
-            out[item] = steps + ix.sa[row / (bwtint)ix.sa_intv];
+            out[item] = (bwtint)steps + sa_sample(ix, row / (bwtint)ix.sa_intv);
             item += stride; have = false;
         }
     }

@@ -28,7 +28,7 @@ struct Hit {
 };
 
 // per-read records of the samse stage for reads finished on the device
-struct SelRec { bwtint sa; int32_t c1, c2; uint8_t type, n_mm, n_gapo, n_gape; int8_t ref_shift; uint8_t score, pad[2]; };   // 20 B
+struct SelRec { bwtint sa; int32_t c1, c2; uint8_t type, n_mm, n_gapo, n_gape; int8_t ref_shift; uint8_t score, pad[2]; };   // 24 B
 struct FinRec { int64_t pos; uint8_t strand, mapq, type, pad[5]; };                                                        // 16 B
 struct DevCigar { int64_t g; int32_t n; uint32_t c[PS_HIT_CIGAR]; };
 // a read finished on the host: several best-score intervals (sequential tie-break), alternative hits, or a larger tier

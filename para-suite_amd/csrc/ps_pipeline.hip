@@ -313,10 +313,14 @@ static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases
         a.big_cap = 65535; a.n_big = (uint32_t)std::min<int64_t>(ctx->n_big, std::max(64, n));
         a.big_pool = ctx->ws_get<uint8_t>("big_pool", (size_t)a.n_big * a.big_cap * 16);
         a.big_next = queue + 4;                                  // second counter in the zeroed queue words
+        a.big_busy = ctx->ws_get<uint32_t>("big_busy", a.n_big);
+        PS_HIP(hipMemsetAsync(a.big_busy, 0, (size_t)a.n_big * 4, s));
     }
     uint32_t *riters = nullptr;
     if (ctx->want_read_iters) { riters = ctx->ws_get<uint32_t>("riters", n); PS_HIP(hipMemsetAsync(riters, 0, (size_t)n * 4, s)); a.read_iters = riters; }
-    { EvTimer t(s); launch_backtrack(a, ctx->ws_get<BtArgs>("btargs", 1), blocks, lm, s); PS_HIP(hipGetLastError()); b.tm.ms_backtrack += t.stop(); ++b.tm.n_backtrack_launches; }
+    { EvTimer t(s); launch_backtrack(a, ctx->ws_get<BtArgs>("btargs", 1), blocks, lm, s); PS_HIP(hipGetLastError());
+      const double ms = t.stop(); b.tm.ms_backtrack += ms; ++b.tm.n_backtrack_launches;
+      if (std::getenv("PS_VERBOSE")) std::fprintf(stderr, "[parasuite-hip]   backtrack launch: %d reads x %d bp, stack %u%s, %d lanes, %.1f ms\n", n, len, pool_cap, wide ? " (wide)" : "", n_lanes, ms); }
     if (ctx->want_read_iters) { ctx->read_iters.resize(n); PS_HIP(hipMemcpyAsync(ctx->read_iters.data(), riters, (size_t)n * 4, hipMemcpyDeviceToHost, s)); PS_HIP(hipStreamSynchronize(s)); }
 }
 
@@ -759,9 +763,9 @@ static int approx_mapq(const Hit &h, const Options &o, int len)
 }
 
 // text position of an SA row -> forward coordinate of the alignment's first base and its strand
-static int64_t to_forward(uint32_t pos_f32, int64_t l_pac, int ref_len, int &strand)
+static int64_t to_forward(bwtint pos_t, int64_t l_pac, int ref_len, int &strand)
 {
-    int64_t pos_f = (int64_t)pos_f32;
+    int64_t pos_f = (int64_t)pos_t;
     strand = 0;
     if (pos_f < l_pac && l_pac < pos_f + ref_len) return -1;       // spans the forward/reverse junction
     const bool is_rev = pos_f >= l_pac;

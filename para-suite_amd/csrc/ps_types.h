@@ -19,11 +19,12 @@
 
 namespace ps {
 
-// Row / text coordinate.  Round 1: one BWT of forward+reverse-complement text
-// with 2*l_pac < 2^32-1 (genomes up to ~2.1 Gbp); hg19 (n = 6.27e9) needs the
-// 40-bit variant planned in DESIGN.md.
-typedef uint32_t bwtint;
-static const bwtint PS_NIL_ROW = 0xFFFFFFFFu;
+// Row / text coordinate of the BWT of forward+reverse-complement text.  Rows are 33-bit quantities
+// (2*l_pac < 2^33: genomes up to 4.29 Gbp, hg19 has n = 6.27e9 rows): 64-bit in registers, 32 bits + one
+// packed high bit wherever they are stored in bulk (narrow stack entries, sampled SA).  Occ counts of one
+// symbol stay below 2^32 (checked when the index is built), so block counters and interval sizes are 32-bit.
+typedef uint64_t bwtint;
+static const bwtint PS_MAX_ROWS = (1ull << 33) - 64;
 
 // ---- FM index: one 64-byte block per 192 BWT symbols --------------------
 // cnt[c] = occurrences of c in all earlier blocks; sym[0..5] = low bit plane,
@@ -35,7 +36,8 @@ struct OccBlock { uint32_t cnt[4]; uint32_t sym[12]; };
 
 struct IndexView {
     const OccBlock *blocks;   // n_blocks
-    const bwtint   *sa;       // SA[row] for row % sa_intv == 0 (row over T$: n+1 rows); sa[0] = 0xFFFFFFFF
+    const uint32_t *sa;       // low 32 bits of SA[row] for row % sa_intv == 0 (row over T$: n+1 rows); entry 0 stands for -1
+    const uint32_t *sa_hi;    // bit 32 of the same samples, 32 per word (stored right behind the low words)
     const uint8_t  *pac;      // forward strand, 2 bit, base p at byte p>>2, bits ((~p)&3)<<1
     bwtint seq_len;           // n = 2*l_pac
     bwtint primary;           // row of the '$' character in the last column
@@ -65,7 +67,6 @@ struct Entry {
     uint16_t score, units;
     uint8_t i, last_diff_pos, n_mm, n_gapo, n_gape, n_ins, n_del, state;
     uint32_t next;
-    uint32_t pad[2];
 };
 static const uint32_t PS_NIL = 0xFFFFFFFFu;
 enum { ST_M = 0, ST_I = 1, ST_D = 2 };
@@ -74,8 +75,8 @@ enum { ST_M = 0, ST_I = 1, ST_D = 2 };
 struct AlnRec {
     bwtint k, l;
     uint16_t score, units;
-    uint8_t n_mm, n_gapo, n_gape, n_ins, n_del, pad[3];
-};  // 20 B
+    uint8_t n_mm, n_gapo, n_gape, n_ins, n_del, pad[7];
+};  // 32 B
 
 enum { RS_OK = 0, RS_OVERFLOW_POOL = 1, RS_OVERFLOW_ALN = 2, RS_BAD_SCORE = 3 };
 
@@ -99,9 +100,10 @@ struct BtArgs {
     void *pool; uint32_t pool_cap;                    // per lane: pool_cap entries (16 B narrow / 32 B wide)
     uint32_t *heads;                                  // wide stack only: heads[lane*PS_MAX_BUCKETS + bucket]
     int wide;
-    // large stack slots for the few reads that outgrow their private slice (narrow stack only): taken with one
-    // atomic, the private entries are copied over by the whole wave, indices stay valid
-    uint8_t *big_pool; uint32_t big_cap, n_big; uint32_t *big_next;
+    // large stack slots for the few reads that outgrow their private slice (narrow stack only): claimed with a
+    // compare-and-swap on the slot's busy word, the private entries are copied over by the whole wave (indices
+    // stay valid), released when the read is done
+    uint8_t *big_pool; uint32_t big_cap, n_big; uint32_t *big_busy; uint32_t *big_next;
     uint32_t *queue;                                  // next unassigned read (waves take chunks of it)
     uint32_t *read_iters;                             // optional: iterations spent per read (profiling aid)
     int hit_min;                                      // lanes with a pending hit a wave collects before it records them

@@ -12,7 +12,7 @@
 using namespace ps;
 
 struct SimIndex {
-    std::vector<OccBlock> blocks; std::vector<bwtint> sa; std::vector<uint8_t> pac;
+    std::vector<OccBlock> blocks; std::vector<uint32_t> sa; std::vector<uint8_t> pac;
     IndexView v;
 };
 
@@ -29,11 +29,14 @@ void *hs_index_new(const uint8_t *bwt_syms, uint64_t n, uint64_t primary, const 
         blk_pack(s->blocks[b], bwt_syms + (beg < n ? beg : 0), (int)m, cnt);
         for (uint64_t t = 0; t < m; ++t) ++cnt[bwt_syms[beg + t]];
     }
-    s->sa.resize(n_sa);
-    for (uint64_t i = 0; i < n_sa; ++i) s->sa[i] = (bwtint)sa_samples[i];
+    s->sa.assign(n_sa + (n_sa + 31) / 32, 0);               // low words, then the bit-32 plane (the product's layout)
+    for (uint64_t i = 0; i < n_sa; ++i) {
+        s->sa[i] = (uint32_t)sa_samples[i];
+        if (i && ((sa_samples[i] >> 32) & 1)) s->sa[n_sa + (i >> 5)] |= 1u << (i & 31);
+    }
     s->pac.assign(pac, pac + l_pac / 4 + 1);
     IndexView &v = s->v;
-    v.blocks = s->blocks.data(); v.sa = s->sa.data(); v.pac = s->pac.data();
+    v.blocks = s->blocks.data(); v.sa = s->sa.data(); v.sa_hi = s->sa.data() + n_sa; v.pac = s->pac.data();
     v.seq_len = (bwtint)n; v.primary = (bwtint)primary; v.l_pac = (bwtint)l_pac;
     v.L2[0] = 0; for (int c = 0; c < 4; ++c) v.L2[c + 1] = v.L2[c] + cnt[c];
     v.n_blocks = nb; v.n_sa = (uint32_t)n_sa; v.sa_intv = sa_intv;
@@ -49,12 +52,12 @@ uint32_t hs_occ(void *p, int64_t k, int c) // Occ(k,c) through the block code, k
     occ_pair1(s->v, (bwtint)(k + 1), (bwtint)(k < 0 ? 0 : k), c, ok, ol, st);
     return ok;
 }
-uint32_t hs_sa(void *p, uint64_t row)
+uint64_t hs_sa(void *p, uint64_t row)
 {
     SimIndex *s = (SimIndex *)p; LaneStats st; memset(&st, 0, sizeof st);
     bwtint r = (bwtint)row; uint32_t steps = 0;
     while (sa_walk_step(s->v, r, steps, st)) {}
-    return steps + s->v.sa[r / s->v.sa_intv];
+    return (bwtint)steps + sa_sample(s->v, r / (bwtint)s->v.sa_intv);
 }
 
 // Width stage + backtracking stage for n_reads reads of one length, simulated with n_lanes lanes.
@@ -147,7 +150,7 @@ int hs_aln(void *p, const Model *md, int n_reads, int len, const uint8_t *codes,
 }
 
 // banded global alignment of query codes against pac[rb, rb+tlen)
-int hs_banded(void *p, int qlen, const uint8_t *q, uint32_t rb, int tlen, int w, uint32_t *cigar, int cap)
+int hs_banded(void *p, int qlen, const uint8_t *q, uint64_t rb, int tlen, int w, uint32_t *cigar, int cap)
 {
     SimIndex *s = (SimIndex *)p;
     std::vector<int32_t> H(qlen + 2), E(qlen + 2);
@@ -165,6 +168,44 @@ int hs_model_profile(const double *P, double ins, double del, int x, int len, Mo
 {
     Options o; std::string err; profile_costs(o, P, ins, del, x);
     return make_model(o, len, *out, err) ? 0 : -1;
+}
+// 33-bit rows: the packed representations must round-trip values above 2^32 (no genome that large fits a CPU test)
+int hs_unit_rows33(void)
+{
+    const bwtint big[] = {0ull, 1ull, 0xFFFFFFFFull, 0x100000000ull, 0x100000001ull, 0x1ABCDEF12ull, PS_MAX_ROWS};
+    for (bwtint k : big) for (bwtint l : big) {
+        if (l < k) continue;
+        // narrow stack entry
+        std::vector<uint8_t> lmem(4096, 0), pool(64 * sizeof(Entry16), 0);
+        BtLane L; memset(&L, 0, sizeof L); L.free_head = PS_NIL; L.cap = 64;
+        BtMem m; bt_mem_bind(m, lmem.data(), 50, 32); m.pool = pool.data(); m.heads = nullptr;
+        push16(L, m, true, k, l, e16_a(17, true, 3, ST_D, 2, 5), e16_b(7, 6, 9), 9);
+        BtArgs a; memset(&a, 0, sizeof a); a.md.profile = 1;
+        bt_pop<false>(a, L, m);
+        if (L.k != k || L.l != l || L.i != 17 || L.n_mm != 3 || L.state != ST_D || L.n_gapo != 2 || L.n_gape != 5 || L.n_ins != 7 || L.n_del != 6 || L.score != 9) return 1;
+        // general narrow push and the wide entry
+        BtArgs aw; memset(&aw, 0, sizeof aw); aw.md.n_buckets = 64; aw.pool_cap = 64; aw.md.profile = 1;
+        memset(&L, 0, sizeof L); L.free_head = PS_NIL; L.cap = 64; L.max_units = 100;
+        bt_push<false>(aw, L, m, true, 21, k, l, 4, 1, 2, 3, 0, ST_I, true, 11, 11);
+        bt_pop<false>(aw, L, m);
+        if (L.k != k || L.l != l || L.i != 21 || L.n_ins != 3 || L.n_del != 0 || L.score != 11) return 2;
+        std::vector<uint8_t> wpool(64 * sizeof(Entry), 0); std::vector<uint32_t> heads(PS_MAX_BUCKETS, 0);
+        m.pool = wpool.data(); m.heads = heads.data();
+        memset(&L, 0, sizeof L); L.free_head = PS_NIL; L.max_units = 100;
+        bt_push<true>(aw, L, m, true, 21, k, l, 4, 1, 2, 3, 0, ST_I, true, 11, 11);
+        bt_pop<true>(aw, L, m);
+        if (L.k != k || L.l != l || L.i != 21) return 3;
+    }
+    for (bwtint sidx : big) {                                  // block addressing
+        int off = -1; const uint32_t b = blk_of(sidx, off);
+        if ((bwtint)b != sidx / PS_BLK_SYMS || (bwtint)off != sidx % PS_BLK_SYMS) return 4;
+    }
+    if (width32(0, 0x17FFFFFFFull) != 0xFFFFFFFFu || width32(5, 5) != 1u || width32(0x100000000ull, 0x100000009ull) != 10u) return 5;
+    // sampled SA with the bit-32 plane
+    uint32_t sa[4 + 1] = {0xFFFFFFFFu, 7u, 0x80000000u, 5u, 0u}; sa[4] = (1u << 3) | (1u << 1);
+    IndexView v; memset(&v, 0, sizeof v); v.sa = sa; v.sa_hi = sa + 4;
+    if (sa_sample(v, 0) != ~(bwtint)0 || sa_sample(v, 1) != 0x100000007ull || sa_sample(v, 2) != 0x80000000ull || sa_sample(v, 3) != 0x100000005ull) return 6;
+    return 0;
 }
 size_t hs_sizeof_model(void) { return sizeof(Model); }
 size_t hs_sizeof_alnrec(void) { return sizeof(AlnRec); }

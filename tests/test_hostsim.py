@@ -13,8 +13,8 @@ import orc
 import simulate as S
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-ALNREC = np.dtype([("k", "<u4"), ("l", "<u4"), ("score", "<u2"), ("units", "<u2"), ("n_mm", "u1"), ("n_gapo", "u1"),
-                   ("n_gape", "u1"), ("n_ins", "u1"), ("n_del", "u1"), ("pad", "u1", 3)])
+ALNREC = np.dtype([("k", "<u8"), ("l", "<u8"), ("score", "<u2"), ("units", "<u2"), ("n_mm", "u1"), ("n_gapo", "u1"),
+                   ("n_gape", "u1"), ("n_ins", "u1"), ("n_del", "u1"), ("pad", "u1", 7)])
 
 
 @pytest.fixture(scope="module")
@@ -27,13 +27,13 @@ def hs():
     H.hs_occ.argtypes = [C.c_void_p, C.c_int64, C.c_int]
     H.hs_occ.restype = C.c_uint32
     H.hs_sa.argtypes = [C.c_void_p, C.c_uint64]
-    H.hs_sa.restype = C.c_uint32
+    H.hs_sa.restype = C.c_uint64
     H.hs_sizeof_model.restype = C.c_size_t
     H.hs_sizeof_alnrec.restype = C.c_size_t
     H.hs_model_stock.argtypes = [C.c_char_p, C.c_int, C.c_void_p]
     H.hs_model_profile.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int, C.c_void_p]
     H.hs_aln.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 7
-    H.hs_banded.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    H.hs_banded.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_int]
     assert H.hs_sizeof_alnrec() == ALNREC.itemsize
     return H
 
@@ -56,7 +56,7 @@ def test_occ_blocks_and_sa_walk(hs, sim_index, example):
         for c in range(4):
             assert hs.hs_occ(sim_index, int(k), c) == ix.occ(int(k), c), (k, c)
     for k in list(rng.integers(0, ix.seq_len + 1, 1500)) + [0, ix.primary, ix.seq_len]:
-        assert hs.hs_sa(sim_index, int(k)) == ix.sa(int(k)) & 0xFFFFFFFF
+        assert hs.hs_sa(sim_index, int(k)) == ix.sa(int(k))
 
 
 def _run(hs, h, model, codes, n_lanes=64, pool_cap=4096, aln_cap=64, wide=0, n_big=0):
@@ -163,3 +163,9 @@ def test_banded_dp_matches_oracle(hs, sim_index, example):
         n = hs.hs_banded(sim_index, 50, q.ctypes.data, p, tlen, w, cig, 16)
         got = [(c >> 4, "MIDS"[c & 0xF]) for c in cig[:n]]
         assert got == orc.ksw_global(q, t, w), trial
+
+
+def test_rows_above_32_bits_round_trip(hs):
+    """33-bit rows (hg19 has 6.27e9): stack entries, block addressing, width saturation, sampled SA with its bit-32 plane."""
+    hs.hs_unit_rows33.restype = C.c_int
+    assert hs.hs_unit_rows33() == 0
