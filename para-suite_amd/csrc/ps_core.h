@@ -31,11 +31,19 @@ PS_HD uint32_t pfx_mask32(int ns) // mask of the first ns (<=32) symbols of a 32
 
 struct Blk { uint32_t x[16]; };  // cnt[4] + lo[6] + hi[6]
 
+// The kernels take their arguments from a struct in device memory, so the compiler sees generic pointers and
+// would emit FLAT loads/stores (which also tie up the LDS counter).  The hot accesses state the address space.
+#ifdef __HIP_DEVICE_COMPILE__
+#define PS_AS_GLOBAL(T, p) ((const __attribute__((address_space(1))) T *)(p))
+#define PS_AS_GLOBAL_W(T, p) ((__attribute__((address_space(1))) T *)(p))
+typedef uint32_t ps_u32x4 __attribute__((ext_vector_type(4)));
+#endif
+
 PS_HD void load_blk(const OccBlock *blocks, uint32_t b, Blk &o)
 {
 #ifdef __HIP_DEVICE_COMPILE__
-    const uint4 *p = reinterpret_cast<const uint4 *>(blocks + b);
-    uint4 a = p[0], c = p[1], d = p[2], e = p[3];
+    const __attribute__((address_space(1))) ps_u32x4 *p = PS_AS_GLOBAL(ps_u32x4, blocks + b);
+    const ps_u32x4 a = p[0], c = p[1], d = p[2], e = p[3];
     o.x[0] = a.x; o.x[1] = a.y; o.x[2] = a.z; o.x[3] = a.w;
     o.x[4] = c.x; o.x[5] = c.y; o.x[6] = c.z; o.x[7] = c.w;
     o.x[8] = d.x; o.x[9] = d.y; o.x[10] = d.z; o.x[11] = d.w;
@@ -107,14 +115,15 @@ PS_HD bwtint L2_of(const IndexView &ix, int c)
     return b1 ? hi : lo;
 }
 // cost of reading text symbol c where the (reverse-complemented) read has s: four byte lanes per read symbol
-PS_HD int cost_of(const uint32_t pk[5], int s, int c)
+PS_HD uint32_t cost_word(const uint32_t pk[5], int s)        // the four costs of read symbol s, one per byte
 {
-    const uint32_t w = s >= 4 ? pk[4] : sel4s(pk[0], pk[1], pk[2], pk[3], s);
-    return (int)((w >> (8 * c)) & 0xffu);
+    const uint32_t w = sel4s(pk[0], pk[1], pk[2], pk[3], s);
+    return s >= 4 ? pk[4] : w;
 }
+PS_HD int cost_of(const uint32_t pk[5], int s, int c) { return (int)((cost_word(pk, s) >> (8 * c)) & 0xffu); }
 
 // row (0..n) of the BW matrix of T$ -> index into the stored BWT (the '$' row is not stored)
-PS_HD bwtint row_to_stored(const IndexView &ix, bwtint row) { return row - (row >= ix.primary ? 1u : 0u); }
+PS_HD bwtint row_to_stored(bwtint primary, bwtint row) { return row - (row >= primary ? 1u : 0u); }
 // stored symbol index -> its 192-symbol block and the offset inside it (32-bit arithmetic: s < 2^33)
 PS_HD uint32_t blk_of(bwtint s, int &off)
 {
@@ -128,17 +137,17 @@ PS_HD uint32_t width32(bwtint k, bwtint l) { const bwtint w = l - k + 1; return 
 struct LaneStats { uint32_t pairs, same, nodes, pushes, pops, iters, exact, lf; };
 
 // Occ(k-1, .) and Occ(l, .) for all four symbols: the memory operation of one search step.
-PS_HD void occ_pair4(const IndexView &ix, bwtint k, bwtint l, uint32_t ck[4], uint32_t cl[4], LaneStats &st)
+PS_HD void occ_pair4(const OccBlock *blocks, bwtint primary, bwtint k, bwtint l, uint32_t ck[4], uint32_t cl[4], LaneStats &st)
 {
     int ol_ = 0, ok_ = 0;
-    const uint32_t bl = blk_of(row_to_stored(ix, l), ol_);
+    const uint32_t bl = blk_of(row_to_stored(primary, l), ol_);
     uint32_t bk = bl;
     bool need_k = k != 0;
-    if (need_k) bk = blk_of(row_to_stored(ix, k - 1), ok_);
+    if (need_k) bk = blk_of(row_to_stored(primary, k - 1), ok_);
     Blk xl, xk;
-    load_blk(ix.blocks, bl, xl);
+    load_blk(blocks, bl, xl);
     bool other = need_k && bk != bl;
-    if (other) load_blk(ix.blocks, bk, xk);
+    if (other) load_blk(blocks, bk, xk);
     blk_count4(xl, ol_ + 1, cl);
     if (!need_k) { ck[0] = ck[1] = ck[2] = ck[3] = 0; }
     else if (other) blk_count4(xk, ok_ + 1, ck);
@@ -149,10 +158,10 @@ PS_HD void occ_pair4(const IndexView &ix, bwtint k, bwtint l, uint32_t ck[4], ui
 PS_HD void occ_pair1(const IndexView &ix, bwtint k, bwtint l, int c, uint32_t &ok, uint32_t &ol, LaneStats &st)
 {
     int ol_ = 0, ok_ = 0;
-    const uint32_t bl = blk_of(row_to_stored(ix, l), ol_);
+    const uint32_t bl = blk_of(row_to_stored(ix.primary, l), ol_);
     uint32_t bk = bl;
     bool need_k = k != 0;
-    if (need_k) bk = blk_of(row_to_stored(ix, k - 1), ok_);
+    if (need_k) bk = blk_of(row_to_stored(ix.primary, k - 1), ok_);
     Blk xl, xk;
     load_blk(ix.blocks, bl, xl);
     bool other = need_k && bk != bl;
@@ -215,6 +224,7 @@ struct BtLane {
     unsigned long long best_cnt;
     unsigned long long bm0, bm1;  // non-empty score buckets (two scalars: a dynamically indexed array would live in scratch)
     uint32_t bump, free_head, iters0;
+    uint32_t n_phantom;            // narrow stack: children not stored because the D(i) bound already rules them out (see bt_iter)
     uint32_t cap;                  // capacity of the stack this lane currently uses (private slice, or a large slot after M_GROW)
     LaneStats st;
 };
@@ -232,6 +242,64 @@ PS_HD int lm_bytes(int len, int seed_len, int n_buckets, bool wide)
     n = (n + 3) & ~3;
     if (((n >> 2) & 1) == 0) n += 4;
     return n;
+}
+
+// What every iteration of the backtracking loop needs from the arguments, as a handful of words the kernel
+// keeps in scalar registers for its whole life (BtArgs itself lives in device memory for the rare, non-inlined
+// paths; reading it inside the loop costs a scalar-cache round trip per field and turns a dynamic L2[c]
+// into a vector load).  Small fields are packed four to a word.
+struct BtHot {
+    const OccBlock *blocks; bwtint primary;
+    uint32_t L2lo[4], L2hi;          // C array of the FM index: low words, bit 32 of L2[c] at bit c
+    uint32_t s_pk[5], u_pk[5];       // substitution costs, one word per read symbol (byte c = text symbol)
+    uint32_t p0, p1, p2, p3;
+    uint32_t inv_c_min, max_entries, pool_cap, n_reads;
+    PS_HD int len() const { return (int)(p0 & 0xffu); }
+    PS_HD int seed_len() const { return (int)((p0 >> 8) & 0xffu); }
+    PS_HD int indel_end_skip() const { return (int)((p0 >> 16) & 0xffu); }
+    PS_HD int max_del_occ() const { return (int)(p0 >> 24); }
+    PS_HD int max_gapo() const { return (int)(p1 & 0xfu); }
+    PS_HD int max_gape() const { return (int)((p1 >> 4) & 0xfu); }
+    PS_HD bool mode_gape() const { return ((p1 >> 8) & 1u) != 0; }
+    PS_HD bool use_seed() const { return ((p1 >> 9) & 1u) != 0; }
+    PS_HD bool profile() const { return ((p1 >> 10) & 1u) != 0; }
+    PS_HD bool has_big() const { return ((p1 >> 11) & 1u) != 0; }
+    PS_HD int seed_units() const { return (int)((p1 >> 12) & 0xfffu); }      // max_seed_diff * u_tight
+    PS_HD int u_tight() const { return (int)(p1 >> 24); }
+    PS_HD int s_gapo_ins() const { return (int)(p2 & 0xffu); }
+    PS_HD int s_gape() const { return (int)((p2 >> 8) & 0xffu); }
+    PS_HD int s_gapo_del() const { return (int)((p2 >> 16) & 0xffu); }
+    PS_HD int s_stop() const { return (int)(p2 >> 24); }
+    PS_HD int u_gapo_ins() const { return (int)(p3 & 0xffu); }
+    PS_HD int u_gape() const { return (int)((p3 >> 8) & 0xffu); }
+    PS_HD int u_gapo_del() const { return (int)((p3 >> 16) & 0xffu); }
+    PS_HD int n_buckets() const { return (int)(p3 >> 24); }
+    PS_HD bwtint L2(int c) const     // c known at compile time in unrolled loops
+    { return (bwtint)L2lo[c] | ((bwtint)((L2hi >> c) & 1u) << 32); }
+    PS_HD bwtint L2_dyn(int c) const
+    { return (bwtint)sel4s(L2lo[0], L2lo[1], L2lo[2], L2lo[3], c) | ((bwtint)((L2hi >> c) & 1u) << 32); }
+};
+// false if a field does not fit its packed width (the caller reports the model as unsupported)
+inline bool bt_hot_make(const BtArgs &a, BtHot &h)
+{
+    const Model &md = a.md;
+    h.blocks = a.ix.blocks; h.primary = a.ix.primary; h.L2hi = 0;
+    for (int c = 0; c < 4; ++c) { h.L2lo[c] = (uint32_t)a.ix.L2[c]; h.L2hi |= (uint32_t)((a.ix.L2[c] >> 32) & 1ull) << c; }
+    for (int c = 0; c < 5; ++c) { h.s_pk[c] = md.s_mm_pk[c]; h.u_pk[c] = md.u_mm_pk[c]; }
+    const int seed_units = md.max_seed_diff * md.u_tight;
+    const bool ok = a.len >= 0 && a.len <= 255 && md.seed_len >= 0 && md.seed_len <= 255 && md.indel_end_skip >= 0 && md.indel_end_skip <= 255 &&
+                    md.max_del_occ >= 0 && md.max_del_occ <= 255 && md.max_gapo >= 0 && md.max_gapo <= 15 && md.max_gape >= 0 && md.max_gape <= 15 &&
+                    seed_units >= 0 && seed_units <= 4095 && md.u_tight >= 0 && md.u_tight <= 255 && md.s_stop >= 0 && md.s_stop <= 255 &&
+                    md.s_gapo_ins >= 0 && md.s_gapo_ins <= 255 && md.s_gape >= 0 && md.s_gape <= 255 && md.s_gapo_del >= 0 && md.s_gapo_del <= 255 &&
+                    md.u_gapo_ins >= 0 && md.u_gapo_ins <= 255 && md.u_gape >= 0 && md.u_gape <= 255 && md.u_gapo_del >= 0 && md.u_gapo_del <= 255 &&
+                    md.n_buckets >= 0 && md.n_buckets <= 255 && md.max_entries >= 0 && md.inv_c_min >= 0;
+    h.p0 = (uint32_t)a.len | ((uint32_t)md.seed_len << 8) | ((uint32_t)md.indel_end_skip << 16) | ((uint32_t)md.max_del_occ << 24);
+    h.p1 = (uint32_t)md.max_gapo | ((uint32_t)md.max_gape << 4) | ((md.mode_gape ? 1u : 0u) << 8) | ((md.use_seed ? 1u : 0u) << 9) |
+           ((md.profile ? 1u : 0u) << 10) | ((a.n_big ? 1u : 0u) << 11) | ((uint32_t)seed_units << 12) | ((uint32_t)md.u_tight << 24);
+    h.p2 = (uint32_t)md.s_gapo_ins | ((uint32_t)md.s_gape << 8) | ((uint32_t)md.s_gapo_del << 16) | ((uint32_t)md.s_stop << 24);
+    h.p3 = (uint32_t)md.u_gapo_ins | ((uint32_t)md.u_gape << 8) | ((uint32_t)md.u_gapo_del << 16) | ((uint32_t)md.n_buckets << 24);
+    h.inv_c_min = (uint32_t)md.inv_c_min; h.max_entries = (uint32_t)md.max_entries; h.pool_cap = a.pool_cap; h.n_reads = (uint32_t)a.n_reads;
+    return ok;
 }
 
 struct BtMem {              // views of one lane's slices
@@ -278,7 +346,8 @@ PS_HD int bm_first(const BtLane &L)
 PS_HD void store16(Entry16 *dst, const Entry16 &e)
 {
 #ifdef __HIP_DEVICE_COMPILE__
-    *reinterpret_cast<uint4 *>(dst) = make_uint4(e.k, e.l, e.a, e.b);
+    ps_u32x4 v; v.x = e.k; v.y = e.l; v.z = e.a; v.w = e.b;
+    *PS_AS_GLOBAL_W(ps_u32x4, dst) = v;
 #else
     *dst = e;
 #endif
@@ -286,7 +355,7 @@ PS_HD void store16(Entry16 *dst, const Entry16 &e)
 PS_HD void load16(const Entry16 *src, Entry16 &e)
 {
 #ifdef __HIP_DEVICE_COMPILE__
-    uint4 v = *reinterpret_cast<const uint4 *>(src);
+    const ps_u32x4 v = *PS_AS_GLOBAL(ps_u32x4, src);
     e.k = v.x; e.l = v.y; e.a = v.z; e.b = v.w;
 #else
     e = *src;
@@ -317,12 +386,12 @@ PS_HD void load_entry(const Entry *src, Entry &e)
 // caller's condition for this child: the narrow path is written with selects and ONE predicated region,
 // because every taken branch costs a divergent wave far more than a few masked instructions.
 template <bool WIDE>
-PS_HD void bt_push(const BtArgs &a, BtLane &L, BtMem &m, bool want, int i, bwtint k, bwtint l, int n_mm, int n_gapo, int n_gape,
+PS_HD void bt_push(const BtHot &a, BtLane &L, BtMem &m, bool want, int i, bwtint k, bwtint l, int n_mm, int n_gapo, int n_gape,
                    int n_ins, int n_del, int state, bool is_diff, int score, int units)
 {
     if (WIDE) {
         if (!want || units > L.max_units) return;        // unaffordable children are not pushed (no-op with stock costs)
-        if (score >= a.md.n_buckets) { L.status = RS_BAD_SCORE; return; }
+        if (score >= a.n_buckets()) { L.status = RS_BAD_SCORE; return; }
         Entry *pool = reinterpret_cast<Entry *>(m.pool);
         uint32_t idx;
         if (L.free_head != PS_NIL) { idx = L.free_head; L.free_head = pool[idx].next; }
@@ -340,7 +409,7 @@ PS_HD void bt_push(const BtArgs &a, BtLane &L, BtMem &m, bool want, int i, bwtin
         ++L.n_stack; ++L.st.pushes;
     } else {
         const bool afford = want && units <= L.max_units;              // unaffordable children are not pushed
-        const bool in_range = score < a.md.n_buckets;                   // always true (make_model sizes the buckets); guards the heads
+        const bool in_range = score < a.n_buckets();                   // always true (make_model sizes the buckets); guards the heads
         const bool reuse = L.free_head != PS_NIL;                       // the slot of the entry popped last is reused first
         const bool have_slot = reuse || L.bump < a.pool_cap;
         const bool go = afford && in_range && have_slot;
@@ -400,7 +469,7 @@ PS_HD void push16(BtLane &L, BtMem &m, bool go, bwtint k, bwtint l, uint32_t wa,
 }
 // up to four children that differ only in their interval (the deletion children): one head read, one head write.
 // Child c covers rows [L2[c]+ck[c]+1, L2[c]+cl[c]], non-empty iff ck[c] < cl[c].
-PS_HD void push16_group(BtLane &L, BtMem &m, bool go_all, const IndexView &ix, const uint32_t ck[4], const uint32_t cl[4], uint32_t wa, uint32_t wb, int score)
+PS_HD void push16_group(BtLane &L, BtMem &m, bool go_all, const BtHot &ix, const uint32_t ck[4], const uint32_t cl[4], uint32_t wa, uint32_t wb, int score)
 {
     const unsigned long long bit = 1ull << score;
     bool any = false;
@@ -411,7 +480,7 @@ PS_HD void push16_group(BtLane &L, BtMem &m, bool go_all, const IndexView &ix, c
         const bool go = go_all && ck[j] < cl[j];
         const uint32_t idx = slot16(L, go);
         if (go) {
-            const bwtint k = ix.L2[j] + ck[j] + 1, l = ix.L2[j] + cl[j];
+            const bwtint k = ix.L2(j) + ck[j] + 1, l = ix.L2(j) + cl[j];
             Entry16 e; e.k = (uint32_t)k; e.l = (uint32_t)l; e.a = wa; e.b = wb | (next << 16) | e16_hi(k, l);
             store16(reinterpret_cast<Entry16 *>(m.pool) + idx, e);
             next = idx;
@@ -425,7 +494,7 @@ PS_HD void push16_group(BtLane &L, BtMem &m, bool go_all, const IndexView &ix, c
 
 // pop the newest entry of the lowest non-empty score bucket into the lane's current-entry registers
 template <bool WIDE>
-PS_HD void bt_pop(const BtArgs &a, BtLane &L, BtMem &m)
+PS_HD void bt_pop(const BtHot &a, BtLane &L, BtMem &m)
 {
     const int b = bm_first(L);
     if (WIDE) {
@@ -452,7 +521,7 @@ PS_HD void bt_pop(const BtArgs &a, BtLane &L, BtMem &m)
         L.n_ins = (int)(e.b & 7); L.n_del = (int)((e.b >> 4) & 7);
         L.score = (int)((e.b >> 8) & 0xff);
         // units are not stored: profile mode has units == score, stock counts every edit as one unit
-        L.units = a.md.profile ? L.score : L.n_mm + L.n_gapo + (a.md.mode_gape ? L.n_gape : 0);
+        L.units = a.profile() ? L.score : L.n_mm + L.n_gapo + (a.mode_gape() ? L.n_gape : 0);
     }
     --L.n_stack; ++L.st.pops;
 }
@@ -493,7 +562,13 @@ PS_COLD void bt_hit(const BtArgs &a, BtLane &L, BtMem &m)
             uint32_t w = a.w[off];
             int bid = m.cw[i] & 0x7f;
             if (w > x) { w -= x; a.w[off] = w; }
-            else if (w == x) { bid = 1; w = shadow - (++j); a.w[off] = w; }
+            else if (w == x) {
+                // positions left of the hit's last difference matched exactly, so their bound was 0 and only ever
+                // rises; should a bound drop after all, children skipped on the strength of it (n_phantom) might have
+                // been viable: the read is redone by the wide tier, which skips nothing
+                if (bid > 1 && !a.wide && L.n_phantom) L.status = RS_OVERFLOW_POOL;
+                bid = 1; w = shadow - (++j); a.w[off] = w;
+            }
             m.cw[i] = cw_pack(bid, i > 0 && w == prev);
             prev = w;
         }
@@ -535,7 +610,7 @@ PS_COLD bool bt_fetch(const BtArgs &a, BtLane &L, BtMem &m, int fetch_r)
         if (nNu > md.max_units) { bt_finish_read(a, L); return false; }
         L.k = 0; L.l = a.ix.seq_len; L.i = len; L.score = 0; L.units = 0;
         L.n_mm = L.n_gapo = L.n_gape = L.n_ins = L.n_del = 0; L.state = ST_M; L.ldp = 0;
-        L.have_cur = true; L.n_stack = 0; L.bm0 = L.bm1 = 0; L.bump = 0; L.free_head = PS_NIL; L.cap = a.pool_cap;
+        L.have_cur = true; L.n_stack = 0; L.bm0 = L.bm1 = 0; L.bump = 0; L.free_head = PS_NIL; L.cap = a.pool_cap; L.n_phantom = 0;
         L.best_score = 1 << 29; L.max_units = md.max_units; L.best_cnt = 0;
         return true;
 }
@@ -545,10 +620,9 @@ PS_COLD bool bt_fetch(const BtArgs &a, BtLane &L, BtMem &m, int fetch_r)
 // serve_hit: lanes that reached a hit (M_HIT) record it now; the kernel batches this rare, long path over
 // several lanes of a wave instead of running it for one lane at a time.
 template <bool WIDE>
-PS_HD void bt_iter(const BtArgs &a, BtLane &L, BtMem &m, int fetch_r, bool serve_hit)
+PS_HD void bt_iter(const BtArgs &a, const BtHot &h, BtLane &L, BtMem &m, int fetch_r, bool serve_hit)
 {
-    const Model &md = a.md;
-    const int len = a.len;
+    const int len = h.len();
     if (L.mode == M_EXIT || L.mode == M_GROW) return;   // retired lane / lane waiting for a larger stack: nothing to do here
     ++L.st.iters;
     if (L.mode == M_HIT) {
@@ -559,7 +633,7 @@ PS_HD void bt_iter(const BtArgs &a, BtLane &L, BtMem &m, int fetch_r, bool serve
     }
     if (L.mode == M_FETCH) {
         if (fetch_r < 0) return;
-        if (fetch_r >= a.n_reads) { L.mode = M_EXIT; return; }
+        if (fetch_r >= (int)h.n_reads) { L.mode = M_EXIT; return; }
         { BtLane t = L; const bool ok = bt_fetch(a, t, m, fetch_r); L = t; if (!ok) return; }   // by-value round trip: only the copy is address-taken
         L.mode = M_POP;
     }
@@ -569,16 +643,21 @@ PS_HD void bt_iter(const BtArgs &a, BtLane &L, BtMem &m, int fetch_r, bool serve
 #pragma unroll 1
         for (int tries = 0; tries < PS_POP_TRIES; ++tries) {
             int n_virtual = L.n_stack + (L.have_cur ? 1 : 0);
-            if (n_virtual == 0 || n_virtual > md.max_entries || L.status != RS_OK) { bt_finish_read(a, L); return; }
+            if (!WIDE && L.n_phantom && (long long)n_virtual + (long long)L.n_phantom > (long long)h.max_entries) {
+                // with the skipped children counted the stack-size stop rule might have fired: the exact count is
+                // only kept by the wide tier, which stores every child
+                L.status = RS_OVERFLOW_POOL; bt_finish_read(a, L); return;
+            }
+            if (n_virtual == 0 || n_virtual > (int)h.max_entries || L.status != RS_OK) { bt_finish_read(a, L); return; }
             if (L.have_cur) L.have_cur = false;
-            else bt_pop<WIDE>(a, L, m);
-            if (L.score > L.best_score + md.s_stop) { bt_finish_read(a, L); return; }
+            else bt_pop<WIDE>(h, L, m);
+            if (L.score > L.best_score + h.s_stop()) { bt_finish_read(a, L); return; }
             const int rem = L.max_units - L.units;
             if (rem < 0) continue;
-            const int mleft = (int)(((uint32_t)rem * (uint32_t)md.inv_c_min) >> 16);     // rem / c_min
+            const int mleft = (int)(((uint32_t)rem * h.inv_c_min) >> 16);     // rem / c_min
             if (L.i > 0 && mleft < (int)(m.cw[L.i - 1] & 0x7f)) continue;
             if (L.i == 0) { L.mode = M_HIT; return; }
-            if (mleft == 0 && (L.state == ST_M || md.mode_gape || L.n_gape == md.max_gape)) L.mode = M_EXACT;
+            if (mleft == 0 && (L.state == ST_M || h.mode_gape() || L.n_gape == h.max_gape())) L.mode = M_EXACT;
             else L.mode = M_EXPAND;
             break;
         }
@@ -586,7 +665,7 @@ PS_HD void bt_iter(const BtArgs &a, BtLane &L, BtMem &m, int fetch_r, bool serve
     if (L.mode != M_EXACT && L.mode != M_EXPAND) return;
     // ---- the memory step, shared by both search modes: Occ(k-1,.) and Occ(l,.) -> the four child intervals ----
     uint32_t ck[4], cl[4];
-    occ_pair4(a.ix, L.k, L.l, ck, cl, L.st);
+    occ_pair4(h.blocks, h.primary, L.k, L.l, ck, cl, L.st);
     // child interval of text symbol c: rows [L2[c]+ck[c]+1, L2[c]+cl[c]], non-empty iff ck[c] < cl[c]
     if (L.mode == M_EXACT) {          // no difference left: extend exactly, one base per iteration
         const int c = seq_at(m, L.i - 1, len);
@@ -594,7 +673,7 @@ PS_HD void bt_iter(const BtArgs &a, BtLane &L, BtMem &m, int fetch_r, bool serve
         if (c > 3) { L.mode = M_POP; return; }
         const uint32_t ok = sel4(ck, c), ol = sel4(cl, c);
         if (ok >= ol) { L.mode = M_POP; return; }
-        const bwtint base = L2_of(a.ix, c);
+        const bwtint base = h.L2_dyn(c);
         L.k = base + ok + 1; L.l = base + ol; --L.i;
         if (L.i == 0) L.mode = M_HIT;
         return;
@@ -604,17 +683,19 @@ PS_HD void bt_iter(const BtArgs &a, BtLane &L, BtMem &m, int fetch_r, bool serve
         ++L.st.nodes;
         const bwtint occ = L.l - L.k + 1;
         const int rem = L.max_units - L.units;
-        const int mleft = (int)(((uint32_t)rem * (uint32_t)md.inv_c_min) >> 16);
-        const int srem = md.max_seed_diff * md.u_tight - L.units;                  // seed budget, in units like the read budget
-        const int m_seed = srem <= 0 ? 0 : (int)(((uint32_t)srem * (uint32_t)md.inv_c_min) >> 16);
+        const int mleft = (int)(((uint32_t)rem * h.inv_c_min) >> 16);
+        const int srem = h.seed_units() - L.units;                  // seed budget, in units like the read budget
+        const int m_seed = srem <= 0 ? 0 : (int)(((uint32_t)srem * h.inv_c_min) >> 16);
         bool allow_diff = true, allow_M = true;
+        const int bnd_same = i > 0 ? (int)(m.cw[i - 1] & 0x7f) : 0;   // D bound a child at position i must still afford
+        const int bnd_del = (int)(m.cw[i] & 0x7f);                    // ... and a deletion child (it stays at i+1)
         if (i > 0) {
-            int b1 = m.cw[i - 1] & 0x7f, b0 = m.cw[i] & 0x7f;
+            int b1 = bnd_same, b0 = bnd_del;
             bool eq = (m.cw[i] & 0x80) != 0;
             if (b1 > mleft - 1) allow_diff = false;
             else if (b1 == mleft - 1 && b0 == mleft - 1 && eq) allow_M = false;
-            if (md.use_seed) {
-                int ii = i - (len - md.seed_len);
+            if (h.use_seed()) {
+                int ii = i - (len - h.seed_len());
                 if (ii > 0) {
                     int s1 = m.csw[ii - 1] & 0x7f, s0 = m.csw[ii] & 0x7f;
                     bool seq_ = (m.csw[ii] & 0x80) != 0;
@@ -628,28 +709,39 @@ PS_HD void bt_iter(const BtArgs &a, BtLane &L, BtMem &m, int fetch_r, bool serve
         const bwtint ek = L.k, el = L.l;
         const int tmp = e_go + e_ge;
         const int s = seq_at(m, i, len);
-        const bool gap_ok = allow_diff && i >= md.indel_end_skip + tmp && len - i >= md.indel_end_skip + tmp;
+        const bool gap_ok = allow_diff && i >= h.indel_end_skip() + tmp && len - i >= h.indel_end_skip() + tmp;
         if (!WIDE) {
             // ---- narrow stack: lean pushes ----
             if (L.bump + 9u > L.cap) {       // stack full: ask for a large slot once; if that is full too, the read goes to the next tier
-                if (L.cap == a.pool_cap && a.n_big) { L.mode = M_GROW; return; }
+                if (L.cap == h.pool_cap && h.has_big()) { L.mode = M_GROW; return; }
                 L.status = RS_OVERFLOW_POOL; L.mode = M_POP; return;
             }
             const bool from_m = e_st == ST_M, from_i = e_st == ST_I, from_d = e_st == ST_D;
+            // A child is popped only to be dropped when the budget left after it cannot pay for the differences its
+            // remaining bases need at least (the check every pop starts with).  The budget only ever shrinks, so such
+            // a child is dropped whenever it is popped: it is not stored at all, only counted (n_phantom) for the
+            // stack-size stop rule.  In profile mode this is about half of all pops.
+            const uint32_t inv = h.inv_c_min;
+            const uint32_t s_word = cost_word(h.s_pk, s), u_word = cost_word(h.u_pk, s);   // this read base against each text symbol
+            uint32_t phantom = 0;
             // insertion child: opens from M, extends from I
             {
-                const bool open = from_m && e_go < md.max_gapo, ext = from_i && e_ge < md.max_gape;
-                const int sc = e_sc + (open ? md.s_gapo_ins : md.s_gape), un = e_un + (open ? md.u_gapo_ins : md.u_gape);
-                const bool go = gap_ok && (open || ext) && un <= L.max_units;
+                const bool open = from_m && e_go < h.max_gapo(), ext = from_i && e_ge < h.max_gape();
+                const int sc = e_sc + (open ? h.s_gapo_ins() : h.s_gape()), un = e_un + (open ? h.u_gapo_ins() : h.u_gape());
+                const bool cand = gap_ok && (open || ext) && un <= L.max_units;
+                const bool go = cand && (int)(((uint32_t)(L.max_units - un) * inv) >> 16) >= bnd_same;
+                phantom += (cand && !go) ? 1u : 0u;
                 push16(L, m, go, ek, el, e16_a(i, true, e_mm, ST_I, e_go + (open ? 1 : 0), e_ge + (open ? 0 : 1)), e16_b(e_ni + 1, e_nd, sc), sc);
             }
             // deletion children: open from M, extend from D; the four share score, counts and position
             {
-                const bool open = from_m && e_go < md.max_gapo;
-                const bool ext = from_d && e_ge < md.max_gape && ((e_ge + e_go) * md.u_tight < L.max_units || occ < (bwtint)md.max_del_occ);
-                const int sc = e_sc + (open ? md.s_gapo_del : md.s_gape), un = e_un + (open ? md.u_gapo_del : md.u_gape);
-                const bool go = gap_ok && (open || ext) && un <= L.max_units;
-                push16_group(L, m, go, a.ix, ck, cl, e16_a(i + 1, true, e_mm, ST_D, e_go + (open ? 1 : 0), e_ge + (open ? 0 : 1)), e16_b(e_ni, e_nd + 1, sc), sc);
+                const bool open = from_m && e_go < h.max_gapo();
+                const bool ext = from_d && e_ge < h.max_gape() && ((e_ge + e_go) * h.u_tight() < L.max_units || occ < (bwtint)h.max_del_occ());
+                const int sc = e_sc + (open ? h.s_gapo_del() : h.s_gape()), un = e_un + (open ? h.u_gapo_del() : h.u_gape());
+                const bool cand = gap_ok && (open || ext) && un <= L.max_units;
+                const bool go = cand && (int)(((uint32_t)(L.max_units - un) * inv) >> 16) >= bnd_del;
+                if (cand && !go) phantom += (ck[0] < cl[0]) + (ck[1] < cl[1]) + (ck[2] < cl[2]) + (ck[3] < cl[3]);
+                push16_group(L, m, go, h, ck, cl, e16_a(i + 1, true, e_mm, ST_D, e_go + (open ? 1 : 0), e_ge + (open ? 0 : 1)), e16_b(e_ni, e_nd + 1, sc), sc);
             }
             L.mode = M_POP;
             const bool do_mm = allow_diff && allow_M;
@@ -658,34 +750,38 @@ PS_HD void bt_iter(const BtArgs &a, BtLane &L, BtMem &m, int fetch_r, bool serve
                 const int c = (s + j) & 3;
                 const bool is_mm = (j != 4 || s > 3);
                 const uint32_t okc = sel4(ck, c), olc = sel4(cl, c);
-                const bwtint base = L2_of(a.ix, c), k2 = base + okc + 1, l2 = base + olc;
+                const bwtint base = h.L2_dyn(c), k2 = base + okc + 1, l2 = base + olc;
                 const bool ok = okc < olc;
                 if (j < 4 || s > 3) {       // mismatch children (the fourth only for an N in the read)
-                    const int sc = e_sc + cost_of(md.s_mm_pk, s, c), un = e_un + cost_of(md.u_mm_pk, s, c);
-                    push16(L, m, do_mm && ok && is_mm && un <= L.max_units, k2, l2, e16_a(i, true, e_mm + 1, ST_M, e_go, e_ge), e16_b(e_ni, e_nd, sc), sc);
+                    const int sc = e_sc + (int)((s_word >> (8 * c)) & 0xffu), un = e_un + (int)((u_word >> (8 * c)) & 0xffu);
+                    const bool cand = do_mm && ok && is_mm && un <= L.max_units;
+                    const bool go = cand && (int)(((uint32_t)(L.max_units - un) * inv) >> 16) >= bnd_same;
+                    phantom += (cand && !go) ? 1u : 0u;
+                    push16(L, m, go, k2, l2, e16_a(i, true, e_mm + 1, ST_M, e_go, e_ge), e16_b(e_ni, e_nd, sc), sc);
                 }
                 if (j == 4 && ok && !is_mm && (do_mm || s < 4)) {   // the match child: parent's score, pushed last => the next pop
                     L.k = k2; L.l = l2; L.i = i; L.state = ST_M; L.ldp = 0; L.have_cur = true;
                 }
             }
+            L.n_phantom += phantom;
             return;
         }
         if (gap_ok) {
             if (e_st == ST_M) {
-                if (e_go < md.max_gapo) {
-                    bt_push<WIDE>(a, L, m, true, i, ek, el, e_mm, e_go + 1, e_ge, e_ni + 1, e_nd, ST_I, true, e_sc + md.s_gapo_ins, e_un + md.u_gapo_ins);
+                if (e_go < h.max_gapo()) {
+                    bt_push<WIDE>(h, L, m, true, i, ek, el, e_mm, e_go + 1, e_ge, e_ni + 1, e_nd, ST_I, true, e_sc + h.s_gapo_ins(), e_un + h.u_gapo_ins());
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        bt_push<WIDE>(a, L, m, ck[j] < cl[j], i + 1, a.ix.L2[j] + ck[j] + 1, a.ix.L2[j] + cl[j], e_mm, e_go + 1, e_ge, e_ni, e_nd + 1, ST_D, true, e_sc + md.s_gapo_del, e_un + md.u_gapo_del);
+                        bt_push<WIDE>(h, L, m, ck[j] < cl[j], i + 1, h.L2(j) + ck[j] + 1, h.L2(j) + cl[j], e_mm, e_go + 1, e_ge, e_ni, e_nd + 1, ST_D, true, e_sc + h.s_gapo_del(), e_un + h.u_gapo_del());
                 }
             } else if (e_st == ST_I) {
-                if (e_ge < md.max_gape)
-                    bt_push<WIDE>(a, L, m, true, i, ek, el, e_mm, e_go, e_ge + 1, e_ni + 1, e_nd, ST_I, true, e_sc + md.s_gape, e_un + md.u_gape);
+                if (e_ge < h.max_gape())
+                    bt_push<WIDE>(h, L, m, true, i, ek, el, e_mm, e_go, e_ge + 1, e_ni + 1, e_nd, ST_I, true, e_sc + h.s_gape(), e_un + h.u_gape());
             } else {
-                if (e_ge < md.max_gape && ((e_ge + e_go) * md.u_tight < L.max_units || occ < (bwtint)md.max_del_occ)) {
+                if (e_ge < h.max_gape() && ((e_ge + e_go) * h.u_tight() < L.max_units || occ < (bwtint)h.max_del_occ())) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        bt_push<WIDE>(a, L, m, ck[j] < cl[j], i + 1, a.ix.L2[j] + ck[j] + 1, a.ix.L2[j] + cl[j], e_mm, e_go, e_ge + 1, e_ni, e_nd + 1, ST_D, true, e_sc + md.s_gape, e_un + md.u_gape);
+                        bt_push<WIDE>(h, L, m, ck[j] < cl[j], i + 1, h.L2(j) + ck[j] + 1, h.L2(j) + cl[j], e_mm, e_go, e_ge + 1, e_ni, e_nd + 1, ST_D, true, e_sc + h.s_gape(), e_un + h.u_gape());
                 }
             }
         }
@@ -696,16 +792,16 @@ PS_HD void bt_iter(const BtArgs &a, BtLane &L, BtMem &m, int fetch_r, bool serve
                 const int c = (s + j) & 3;
                 const bool is_mm = (j != 4 || s > 3);
                 const uint32_t okc = sel4(ck, c), olc = sel4(cl, c);
-                const bwtint base = L2_of(a.ix, c), k2 = base + okc + 1, l2 = base + olc;
+                const bwtint base = h.L2_dyn(c), k2 = base + okc + 1, l2 = base + olc;
                 const bool ok = okc < olc;
-                bt_push<WIDE>(a, L, m, ok && is_mm, i, k2, l2, e_mm + 1, e_go, e_ge, e_ni, e_nd, ST_M, true, e_sc + cost_of(md.s_mm_pk, s, c), e_un + cost_of(md.u_mm_pk, s, c));
+                bt_push<WIDE>(h, L, m, ok && is_mm, i, k2, l2, e_mm + 1, e_go, e_ge, e_ni, e_nd, ST_M, true, e_sc + cost_of(h.s_pk, s, c), e_un + cost_of(h.u_pk, s, c));
                 if (ok && !is_mm) { // the match child has the parent's score and is pushed last: it is the next pop
                     L.k = k2; L.l = l2; L.i = i; L.state = ST_M; L.ldp = 0; L.have_cur = true;
                 }
             }
         } else if (s < 4) {
             const uint32_t okc = sel4(ck, s), olc = sel4(cl, s);
-            const bwtint base = L2_of(a.ix, s);
+            const bwtint base = h.L2_dyn(s);
             if (okc < olc) { L.k = base + okc + 1; L.l = base + olc; L.i = i; L.state = ST_M; L.ldp = 0; L.have_cur = true; }
         }
     }
@@ -725,7 +821,7 @@ PS_HD bool sa_walk_step(const IndexView &ix, bwtint &row, uint32_t &steps, LaneS
     ++steps; ++st.lf;
     if (row == ix.primary) { row = 0; return true; }
     int pos = 0;
-    const uint32_t b = blk_of(row_to_stored(ix, row), pos);
+    const uint32_t b = blk_of(row_to_stored(ix.primary, row), pos);
     Blk x;
     load_blk(ix.blocks, b, x);
     int c = blk_sym(x, pos);

@@ -26,7 +26,7 @@ struct RefineArgs {
 };
 
 void launch_width(const WidthArgs &a, hipStream_t s);
-void launch_backtrack(const BtArgs &a, const BtArgs *d_args /* device copy, filled here */, int n_blocks, int lm_stride, hipStream_t s);
+bool launch_backtrack(const BtArgs &a, const BtArgs *d_args /* device copy, filled here */, int n_blocks, int lm_stride, hipStream_t s);   // false: model outside the packed ranges
 void launch_sa2pos(const IndexView &ix, const bwtint *rows, bwtint *out, int n, KStats *stats, hipStream_t s);
 void launch_refine(const RefineArgs &a, int n_blocks, hipStream_t s);
 

@@ -75,16 +75,49 @@ __global__ void __launch_bounds__(256) k_width(WidthArgs a)
 }
 
 // ---- seed / backtracking stage --------------------------------------------
+// wave-uniform value pinned in a scalar register (a kernel argument would otherwise be re-read from memory
+// wherever the compiler runs short of registers -- inside the loop)
+__device__ __forceinline__ uint32_t pin32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ unsigned long long pin64(unsigned long long v)
+{
+    return (unsigned long long)pin32((uint32_t)v) | ((unsigned long long)pin32((uint32_t)(v >> 32)) << 32);
+}
+__device__ __forceinline__ void pin_hot(BtHot &h, const BtHot &k)
+{
+    h.blocks = reinterpret_cast<const OccBlock *>(pin64(reinterpret_cast<unsigned long long>(k.blocks)));
+    h.primary = pin64(k.primary);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) h.L2lo[c] = pin32(k.L2lo[c]);
+    h.L2hi = pin32(k.L2hi);
+#pragma unroll
+    for (int c = 0; c < 5; ++c) { h.s_pk[c] = pin32(k.s_pk[c]); h.u_pk[c] = pin32(k.u_pk[c]); }
+    h.p0 = pin32(k.p0); h.p1 = pin32(k.p1); h.p2 = pin32(k.p2); h.p3 = pin32(k.p3);
+    h.inv_c_min = pin32(k.inv_c_min); h.max_entries = pin32(k.max_entries); h.pool_cap = pin32(k.pool_cap); h.n_reads = pin32(k.n_reads);
+}
+
+struct BtLoop {             // loop-level constants of the kernel (same treatment)
+    uint32_t *queue; uint32_t *big_next; uint32_t *big_busy; uint8_t *big_pool;
+    uint32_t n_reads, big_cap, n_big, fetch_min, hit_min;
+};
+
 template <bool WIDE>
-__global__ void __launch_bounds__(256) k_backtrack(const BtArgs *__restrict__ ap, int lm_stride)
+__global__ void __launch_bounds__(256) k_backtrack(const BtArgs *__restrict__ ap, BtHot hk, int lm_stride)
 {
     const BtArgs &a = *ap;      // arguments live in device memory: the cold (non-inlined) paths take their address
+    BtHot h; pin_hot(h, hk);
+    BtLoop lp;
+    lp.queue = reinterpret_cast<uint32_t *>(pin64(reinterpret_cast<unsigned long long>(a.queue)));
+    lp.big_next = reinterpret_cast<uint32_t *>(pin64(reinterpret_cast<unsigned long long>(a.big_next)));
+    lp.big_busy = reinterpret_cast<uint32_t *>(pin64(reinterpret_cast<unsigned long long>(a.big_busy)));
+    lp.big_pool = reinterpret_cast<uint8_t *>(pin64(reinterpret_cast<unsigned long long>(a.big_pool)));
+    lp.n_reads = pin32((uint32_t)a.n_reads); lp.big_cap = pin32(a.big_cap); lp.n_big = pin32(a.n_big);
+    lp.fetch_min = pin32((uint32_t)a.fetch_min); lp.hit_min = pin32((uint32_t)a.hit_min);
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane_g = blockIdx.x * blockDim.x + threadIdx.x;
     BtMem m;
     uint8_t *mine = smem + (size_t)threadIdx.x * lm_stride;
-    bt_mem_bind(m, mine, a.len, a.md.seed_len);
-    uint8_t *const pool_private = reinterpret_cast<uint8_t *>(a.pool) + (size_t)lane_g * a.pool_cap * (WIDE ? sizeof(Entry) : sizeof(Entry16));
+    bt_mem_bind(m, mine, h.len(), h.seed_len());
+    uint8_t *const pool_private = reinterpret_cast<uint8_t *>(a.pool) + (size_t)lane_g * h.pool_cap * (WIDE ? sizeof(Entry) : sizeof(Entry16));
     m.pool = pool_private;
     m.heads = WIDE ? a.heads + (size_t)lane_g * PS_MAX_BUCKETS : nullptr;
     BtLane L;
@@ -102,36 +135,36 @@ __global__ void __launch_bounds__(256) k_backtrack(const BtArgs *__restrict__ ap
     for (;;) {
         const bool want = L.mode == M_FETCH;
         if (!WIDE && want && m.pool != pool_private) {         // read done on a large slot: hand the slot back
-            const unsigned int slot = (unsigned int)((reinterpret_cast<uint8_t *>(m.pool) - a.big_pool) / ((size_t)a.big_cap * sizeof(Entry16)));
+            const unsigned int slot = (unsigned int)((reinterpret_cast<uint8_t *>(m.pool) - lp.big_pool) / ((size_t)lp.big_cap * sizeof(Entry16)));
             __threadfence();                                   // this lane's stores to the slot land before the next owner's
-            atomicExch(a.big_busy + slot, 0u);
+            atomicExch(lp.big_busy + slot, 0u);
             m.pool = pool_private;                             // a new read starts on the lane's private stack slice
         }
         const unsigned long long wmask = __ballot(want), lmask = __ballot(L.mode != M_EXIT), hmask = __ballot(L.mode == M_HIT);
         if (lmask == 0) break;
         const bool stalled = (wmask | hmask) == lmask;          // nobody can advance without being served
-        const bool serve_hit = hmask != 0 && (__popcll(hmask) >= a.hit_min || stalled);
+        const bool serve_hit = hmask != 0 && (__popcll(hmask) >= (int)lp.hit_min || stalled);
         int fetch_r = -1;
         if (wmask) {
             const int cnt = __popcll(wmask);
-            if (cnt >= a.fetch_min || stalled) {
+            if (cnt >= (int)lp.fetch_min || stalled) {
                 const int rank = __popcll(wmask & lane_lt);
                 int served = 0;
                 while (served < cnt) {
                     if (q_next == q_end) {
                         if (exhausted) break;
                         unsigned int base = 0;
-                        if (lane == 0) base = atomicAdd(a.queue, (unsigned int)PS_Q_CHUNK);
+                        if (lane == 0) base = atomicAdd(lp.queue, (unsigned int)PS_Q_CHUNK);
                         base = (unsigned int)__shfl((int)base, 0, 64);
-                        if (base >= (unsigned int)a.n_reads) { exhausted = true; break; }
+                        if (base >= lp.n_reads) { exhausted = true; break; }
                         q_next = (int)base;
-                        q_end = (int)base + PS_Q_CHUNK < a.n_reads ? (int)base + PS_Q_CHUNK : a.n_reads;
+                        q_end = (int)base + PS_Q_CHUNK < (int)lp.n_reads ? (int)base + PS_Q_CHUNK : (int)lp.n_reads;
                     }
                     const int take = q_end - q_next < cnt - served ? q_end - q_next : cnt - served;
                     if (want && rank >= served && rank < served + take) fetch_r = q_next + (rank - served);
                     q_next += take; served += take;
                 }
-                if (want && fetch_r < 0 && exhausted) fetch_r = a.n_reads;   // nothing left: this lane retires
+                if (want && fetch_r < 0 && exhausted) fetch_r = (int)lp.n_reads;   // nothing left: this lane retires
             }
         }
         if (!WIDE) {
@@ -139,27 +172,27 @@ __global__ void __launch_bounds__(256) k_backtrack(const BtArgs *__restrict__ ap
             while (gmask) {                                    // wave-uniform loop over the lanes that need a larger stack
                 const int src = __ffsll((unsigned long long)gmask) - 1;
                 gmask &= gmask - 1;
-                unsigned int slot = a.n_big;
+                unsigned int slot = lp.n_big;
                 if (lane == src) {                             // claim a free slot: rotating start, bounded probing
-                    unsigned int at = atomicAdd(a.big_next, 1u) % a.n_big;
+                    unsigned int at = atomicAdd(lp.big_next, 1u) % lp.n_big;
                     for (int tries = 0; tries < 256; ++tries) {
-                        if (atomicCAS(a.big_busy + at, 0u, 1u) == 0u) { slot = at; break; }
-                        at = at + 1u == a.n_big ? 0u : at + 1u;
+                        if (atomicCAS(lp.big_busy + at, 0u, 1u) == 0u) { slot = at; break; }
+                        at = at + 1u == lp.n_big ? 0u : at + 1u;
                     }
                 }
                 slot = (unsigned int)__shfl((int)slot, src, 64);
                 const unsigned int n_copy = (unsigned int)__shfl((int)L.bump, src, 64);
                 const unsigned long long from = (unsigned long long)__shfl((long long)reinterpret_cast<unsigned long long>(m.pool), src, 64);
-                if (slot < a.n_big) {
+                if (slot < lp.n_big) {
                     const uint4 *sp = reinterpret_cast<const uint4 *>(from);
-                    uint4 *dp = reinterpret_cast<uint4 *>(a.big_pool + (size_t)slot * a.big_cap * sizeof(Entry16));
+                    uint4 *dp = reinterpret_cast<uint4 *>(lp.big_pool + (size_t)slot * lp.big_cap * sizeof(Entry16));
                     for (unsigned int e = (unsigned int)lane; e < n_copy; e += 64u) dp[e] = sp[e];
                     __threadfence();                           // the copies of all lanes are visible before the owner pops from them
-                    if (lane == src) { m.pool = dp; L.cap = a.big_cap; L.mode = M_EXPAND; }
+                    if (lane == src) { m.pool = dp; L.cap = lp.big_cap; L.mode = M_EXPAND; }
                 } else if (lane == src) { L.status = RS_OVERFLOW_POOL; L.mode = M_POP; }
             }
         }
-        bt_iter<WIDE>(a, L, m, fetch_r, serve_hit);
+        bt_iter<WIDE>(a, h, L, m, fetch_r, serve_hit);
     }
     flush_stats(a.stats, L.st);
 }
@@ -217,17 +250,20 @@ void launch_width(const WidthArgs &a, hipStream_t s)
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_width, dim3(blocks), dim3(256), 0, s, a);
 }
-void launch_backtrack(const BtArgs &a, const BtArgs *d_args, int n_blocks, int lm_stride, hipStream_t s)
+bool launch_backtrack(const BtArgs &a, const BtArgs *d_args, int n_blocks, int lm_stride, hipStream_t s)
 {
+    BtHot h;
+    if (!bt_hot_make(a, h)) return false;       // a model field outside its packed range
     (void)hipMemcpyAsync(const_cast<BtArgs *>(d_args), &a, sizeof(BtArgs), hipMemcpyHostToDevice, s);
     const size_t lds = (size_t)256 * lm_stride;
     if (a.wide) {
         if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_backtrack<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_backtrack<true>, dim3(n_blocks), dim3(256), lds, s, d_args, lm_stride);
+        hipLaunchKernelGGL(k_backtrack<true>, dim3(n_blocks), dim3(256), lds, s, d_args, h, lm_stride);
     } else {
         if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_backtrack<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_backtrack<false>, dim3(n_blocks), dim3(256), lds, s, d_args, lm_stride);
+        hipLaunchKernelGGL(k_backtrack<false>, dim3(n_blocks), dim3(256), lds, s, d_args, h, lm_stride);
     }
+    return true;
 }
 void launch_sa2pos(const IndexView &ix, const bwtint *rows, bwtint *out, int n, KStats *stats, hipStream_t s)
 {

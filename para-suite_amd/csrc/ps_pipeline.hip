@@ -318,7 +318,9 @@ static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases
     }
     uint32_t *riters = nullptr;
     if (ctx->want_read_iters) { riters = ctx->ws_get<uint32_t>("riters", n); PS_HIP(hipMemsetAsync(riters, 0, (size_t)n * 4, s)); a.read_iters = riters; }
-    { EvTimer t(s); launch_backtrack(a, ctx->ws_get<BtArgs>("btargs", 1), blocks, lm, s); PS_HIP(hipGetLastError());
+    { EvTimer t(s);
+      if (!launch_backtrack(a, ctx->ws_get<BtArgs>("btargs", 1), blocks, lm, s)) throw Error("cost model outside the ranges the search kernel packs (gap/score fields must fit a byte)");
+      PS_HIP(hipGetLastError());
       const double ms = t.stop(); b.tm.ms_backtrack += ms; ++b.tm.n_backtrack_launches;
       if (std::getenv("PS_VERBOSE")) std::fprintf(stderr, "[parasuite-hip]   backtrack launch: %d reads x %d bp, stack %u%s, %d lanes, %.1f ms\n", n, len, pool_cap, wide ? " (wide)" : "", n_lanes, ms); }
     if (ctx->want_read_iters) { ctx->read_iters.resize(n); PS_HIP(hipMemcpyAsync(ctx->read_iters.data(), riters, (size_t)n * 4, hipMemcpyDeviceToHost, s)); PS_HIP(hipStreamSynchronize(s)); }

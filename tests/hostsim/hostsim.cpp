@@ -112,12 +112,14 @@ int hs_aln(void *p, const Model *md, int n_reads, int len, const uint8_t *codes,
     std::vector<uint8_t> lm((size_t)n_lanes * lmb);
     std::vector<BtLane> lanes(n_lanes); std::vector<int> next(n_lanes);
     for (int t = 0; t < n_lanes; ++t) { memset(&lanes[t], 0, sizeof(BtLane)); lanes[t].mode = M_FETCH; next[t] = t; }
+    BtHot h;
+    if (!bt_hot_make(a, h)) return -2;
     bool any = true;
     while (any) {                                        // lock-step over lanes, like a wave
         any = false;
         for (int t = 0; t < n_lanes; ++t) {
             BtLane &L = lanes[t];
-            if (L.mode == M_EXIT) { BtMem mm{}; bt_iter<false>(a, L, mm, -1, true); continue; }   // the kernel calls retired lanes too: must be a no-op
+            if (L.mode == M_EXIT) { BtMem mm{}; bt_iter<false>(a, h, L, mm, -1, true); continue; }   // the kernel calls retired lanes too: must be a no-op
             BtMem m; uint8_t *mine = lm.data() + (size_t)t * lmb;
             bt_mem_bind(m, mine, len, seed_len);
             uint8_t *priv = pool.data() + (size_t)t * pool_cap * (wide ? sizeof(Entry) : sizeof(Entry16));
@@ -133,7 +135,7 @@ int hs_aln(void *p, const Model *md, int n_reads, int len, const uint8_t *codes,
             m.heads = a.heads + (size_t)t * PS_MAX_BUCKETS;
             int fr = -1;                                   // static hand-out here; the kernel deals reads from a queue
             if (L.mode == M_FETCH) { fr = next[t] < n_reads ? next[t] : n_reads; next[t] += n_lanes; }
-            if (wide) bt_iter<true>(a, L, m, fr, (t & 1) != 0 || L.mode != M_HIT || (L.st.iters & 3) == 0); else bt_iter<false>(a, L, m, fr, (t & 1) != 0 || (L.st.iters & 3) == 0);
+            if (wide) bt_iter<true>(a, h, L, m, fr, (t & 1) != 0 || L.mode != M_HIT || (L.st.iters & 3) == 0); else bt_iter<false>(a, h, L, m, fr, (t & 1) != 0 || (L.st.iters & 3) == 0);
             any = true;
         }
     }
@@ -180,11 +182,12 @@ int hs_unit_rows33(void)
         BtLane L; memset(&L, 0, sizeof L); L.free_head = PS_NIL; L.cap = 64;
         BtMem m; bt_mem_bind(m, lmem.data(), 50, 32); m.pool = pool.data(); m.heads = nullptr;
         push16(L, m, true, k, l, e16_a(17, true, 3, ST_D, 2, 5), e16_b(7, 6, 9), 9);
-        BtArgs a; memset(&a, 0, sizeof a); a.md.profile = 1;
+        BtArgs a0; memset(&a0, 0, sizeof a0); a0.md.profile = 1; a0.md.n_buckets = 64; a0.pool_cap = 64;
+        BtHot a; bt_hot_make(a0, a);
         bt_pop<false>(a, L, m);
         if (L.k != k || L.l != l || L.i != 17 || L.n_mm != 3 || L.state != ST_D || L.n_gapo != 2 || L.n_gape != 5 || L.n_ins != 7 || L.n_del != 6 || L.score != 9) return 1;
         // general narrow push and the wide entry
-        BtArgs aw; memset(&aw, 0, sizeof aw); aw.md.n_buckets = 64; aw.pool_cap = 64; aw.md.profile = 1;
+        const BtHot &aw = a;
         memset(&L, 0, sizeof L); L.free_head = PS_NIL; L.cap = 64; L.max_units = 100;
         bt_push<false>(aw, L, m, true, 21, k, l, 4, 1, 2, 3, 0, ST_I, true, 11, 11);
         bt_pop<false>(aw, L, m);
