@@ -60,9 +60,11 @@ PS_HD void load_blk(const OccBlock *blocks, uint32_t b, Blk &o)
 PS_HD void blk_count4(const Blk &b, int r, uint32_t cnt[4])
 {
     uint32_t c1 = 0, c2 = 0, c3 = 0;
+    const int q = r >> 5;                                   // whole words before the partial one
+    const uint32_t part = (1u << (r & 31)) - 1u;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-        const uint32_t m = pfx_mask32(r - 32 * j), lo = b.x[4 + j] & m, hi = b.x[10 + j] & m;
+        const uint32_t m = j < q ? 0xFFFFFFFFu : (j == q ? part : 0u), lo = b.x[4 + j] & m, hi = b.x[10 + j] & m;
         c3 += ps_popc(lo & hi);
         c2 += ps_popc(hi & ~lo);
         c1 += ps_popc(lo & ~hi);
@@ -149,9 +151,12 @@ PS_HD void occ_pair4(const OccBlock *blocks, bwtint primary, bwtint k, bwtint l,
     bool other = need_k && bk != bl;
     if (other) load_blk(blocks, bk, xk);
     blk_count4(xl, ol_ + 1, cl);
+    // one counting pass for k-1 whichever block it is in (two passes under complementary lane masks would both
+    // be executed by a wave that has lanes of either kind)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) xk.x[j] = other ? xk.x[j] : xl.x[j];
+    blk_count4(xk, need_k ? ok_ + 1 : 0, ck);
     if (!need_k) { ck[0] = ck[1] = ck[2] = ck[3] = 0; }
-    else if (other) blk_count4(xk, ok_ + 1, ck);
-    else blk_count4(xl, ok_ + 1, ck);
     ++st.pairs;
     if (need_k && !other) ++st.same;
 }
