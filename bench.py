@@ -331,6 +331,16 @@ def main():
             "mapped_frac": float((hits["type"] != 0).mean()),
             "overflow_reads": [int(acc["n_overflow_tier1"] / K), int(acc["n_overflow_tier2"] / K)],
         }
+        # HBM traffic of the dominant kernel: PMC passes cannot run inside the timed job, so the committed passes of
+        # the same configuration are quoted (profiles/pmc_traffic.json), null when none matches
+        try:
+            pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            for e in pt["entries"]:
+                if all(res["config"].get(k) == v for k, v in e["match"].items()) and e["kernel"] == res["roofline"]["kernel"]:
+                    res["roofline"]["traffic"] = (e["fetch_kb"] + e["write_kb"]) * 1024.0 / e["launches"]
+                    res["roofline"]["traffic_source"] = e["source"]
+        except Exception:
+            pass
         # ---------------- CPU baseline: the oracle (a port, not the PARA-suite_aligner binary) ----------------
         if world == 1 and args.cpu_sample > 0:
             try:

@@ -229,6 +229,7 @@ struct BtLane {
     unsigned long long best_cnt;
     unsigned long long bm0, bm1;  // non-empty score buckets (two scalars: a dynamically indexed array would live in scratch)
     uint32_t bump, free_head, iters0;
+    uint32_t rn0, rn1;             // N mask of a read of up to 64 bases (read orientation)
     uint32_t n_phantom;            // narrow stack: children not stored because the D(i) bound already rules them out (see bt_iter)
     uint32_t cap;                  // capacity of the stack this lane currently uses (private slice, or a large slot after M_GROW)
     LaneStats st;
@@ -237,10 +238,12 @@ struct BtLane {
 // local per-lane memory (LDS in the kernel), all 4-byte words: compact widths cw (4 positions per word),
 // seed widths csw, the read's 2-bit base words and N-mask words, then -- narrow stack only -- the heads of
 // the score buckets as uint16 entry indices.  The byte count keeps (stride/4) odd so that lanes reading
-// the same offset hit different LDS banks.
+// the same offset hit different LDS banks.  Reads of up to 64 bases keep their N mask in two lane registers
+// instead: those 8 bytes decide between three and four resident workgroups per CU at 50 bp.
 PS_HD int lm_ncw(int len) { return (len + 1 + 3) >> 2; }
 PS_HD int lm_ncsw(int seed_len) { return seed_len > 0 ? (seed_len + 1 + 3) >> 2 : 0; }
-PS_HD int lm_heads_off(int len, int seed_len) { return 4 * (lm_ncw(len) + lm_ncsw(seed_len) + ((len + 15) >> 4) + ((len + 31) >> 5)); }
+PS_HD bool lm_nmask_in_regs(int len) { return len <= 64; }
+PS_HD int lm_heads_off(int len, int seed_len) { return 4 * (lm_ncw(len) + lm_ncsw(seed_len) + ((len + 15) >> 4) + (lm_nmask_in_regs(len) ? 0 : ((len + 31) >> 5))); }
 PS_HD int lm_bytes(int len, int seed_len, int n_buckets, bool wide)
 {
     int n = lm_heads_off(len, seed_len) + (wide ? 0 : 2 * n_buckets);
@@ -323,11 +326,12 @@ PS_HD void bt_mem_bind(BtMem &m, uint8_t *mine, int len, int seed_len)
     m.heads16 = reinterpret_cast<uint16_t *>(mine + lm_heads_off(len, seed_len));
 }
 // base j of the reverse-complemented read (what the search consumes): 0..3, 4 = N
-PS_HD int seq_at(const BtMem &m, int j, int len)
+PS_HD int seq_at(const BtMem &m, const BtLane &L, int j, int len)
 {
     const int p = len - 1 - j;
-    const uint32_t b = (m.rb[p >> 4] >> (2 * (p & 15))) & 3u, n = (m.rn[p >> 5] >> (p & 31)) & 1u;
-    return n ? 4 : 3 - (int)b;
+    const uint32_t b = (m.rb[p >> 4] >> (2 * (p & 15))) & 3u;
+    const uint32_t nw = lm_nmask_in_regs(len) ? (p < 32 ? L.rn0 : L.rn1) : m.rn[p >> 5];
+    return ((nw >> (p & 31)) & 1u) ? 4 : 3 - (int)b;
 }
 
 // The stack of one lane.  NARROW (tiers 1-2): 16-byte entries, bump allocation, bucket heads in LDS --
@@ -607,9 +611,11 @@ PS_COLD bool bt_fetch(const BtArgs &a, BtLane &L, BtMem &m, int fetch_r)
             for (int p = 0; p < a.n_bw; ++p) m.rb[p] = a.bases[(size_t)p * a.n_reads + r];
         }
         int nNu = 0;
+        L.rn0 = L.rn1 = 0;
         for (int p = 0; p < a.n_mw; ++p) {
             uint32_t w = a.nmask[(size_t)p * a.n_reads + r];
-            m.rn[p] = w;
+            if (lm_nmask_in_regs(len)) { if (p == 0) L.rn0 = w; else L.rn1 = w; }
+            else m.rn[p] = w;
             nNu += (int)ps_popc(w) * (int)(md.u_mm_pk[4] & 0xffu);
         }
         if (nNu > md.max_units) { bt_finish_read(a, L); return false; }
@@ -673,7 +679,7 @@ PS_HD void bt_iter(const BtArgs &a, const BtHot &h, BtLane &L, BtMem &m, int fet
     occ_pair4(h.blocks, h.primary, L.k, L.l, ck, cl, L.st);
     // child interval of text symbol c: rows [L2[c]+ck[c]+1, L2[c]+cl[c]], non-empty iff ck[c] < cl[c]
     if (L.mode == M_EXACT) {          // no difference left: extend exactly, one base per iteration
-        const int c = seq_at(m, L.i - 1, len);
+        const int c = seq_at(m, L, L.i - 1, len);
         ++L.st.exact;
         if (c > 3) { L.mode = M_POP; return; }
         const uint32_t ok = sel4(ck, c), ol = sel4(cl, c);
@@ -713,7 +719,7 @@ PS_HD void bt_iter(const BtArgs &a, const BtHot &h, BtLane &L, BtMem &m, int fet
         const int e_sc = L.score, e_un = L.units, e_st = L.state;
         const bwtint ek = L.k, el = L.l;
         const int tmp = e_go + e_ge;
-        const int s = seq_at(m, i, len);
+        const int s = seq_at(m, L, i, len);
         const bool gap_ok = allow_diff && i >= h.indel_end_skip() + tmp && len - i >= h.indel_end_skip() + tmp;
         if (!WIDE) {
             // ---- narrow stack: lean pushes ----

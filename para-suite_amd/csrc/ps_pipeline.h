@@ -32,7 +32,7 @@ struct SelRec { bwtint sa; int32_t c1, c2; uint8_t type, n_mm, n_gapo, n_gape; i
 struct FinRec { int64_t pos; uint8_t strand, mapq, type, pad[5]; };                                                        // 16 B
 struct DevCigar { int64_t g; int32_t n; uint32_t c[PS_HIT_CIGAR]; };
 // a read finished on the host: several best-score intervals (sequential tie-break), alternative hits, or a larger tier
-struct SubRead { int64_t g = 0, easy_before = 0, hard_before = 0; uint8_t cls = 0; std::vector<AlnRec> alns; Hit hit; };
+struct SubRead { int64_t g = 0, easy_before = 0, hard_before = 0; uint8_t cls = 0; const AlnRec *alns = nullptr; int32_t n_alns = 0; Hit hit; };   // alns: into Batch::sub_alns or a Bin's overflow list
 
 struct Timing {
     double ms_width = 0, ms_backtrack = 0, ms_compact = 0, ms_select = 0, ms_sa2pos = 0, ms_refine = 0, ms_host_post = 0, ms_total = 0, ms_classify = 0, ms_rows = 0, ms_sel_hard = 0, ms_sel_easy = 0;
@@ -95,6 +95,7 @@ struct Batch {
     PinBuf p_class, p_sel, p_fin;
     uint8_t *h_class = nullptr; SelRec *h_sel = nullptr; FinRec *h_fin = nullptr;
     std::vector<SubRead> sub; std::vector<Multi> multis; std::vector<DevCigar> dev_cigars;
+    std::vector<std::unique_ptr<PinBuf>> sub_alns;   // per bin: hit lists of the host-finished reads (stride aln_cap)
     int64_t n_class1 = 0, n_hard = 0;
     std::vector<uint64_t> hard_draws_cum;  // draws consumed by the several-best reads up to and including each
     uint64_t draws_in = 0, draws_out = 0;

@@ -270,6 +270,25 @@ struct EvTimer {
 };
 
 
+// host loops over millions of reads: contiguous ranges on a few threads; f(begin, end, thread)
+template <class F> static void par_for(size_t n, int threads, F f)
+{
+    size_t nt = (size_t)std::max(1, threads);
+    if (nt > n / 8192 + 1) nt = n / 8192 + 1;
+    if (nt <= 1) { if (n) f((size_t)0, n, 0); return; }
+    std::vector<std::thread> th;
+    std::vector<std::exception_ptr> err(nt);
+    const size_t per = (n + nt - 1) / nt;
+    for (size_t t = 0; t < nt; ++t)
+        th.emplace_back([&, t]() {
+            const size_t a0 = t * per, b0 = std::min(n, a0 + per);
+            try { if (a0 < b0) f(a0, b0, (int)t); } catch (...) { err[t] = std::current_exception(); }
+        });
+    for (auto &x : th) x.join();
+    for (auto &e : err) if (e) std::rethrow_exception(e);
+}
+static int par_threads(size_t n, int threads) { size_t nt = (size_t)std::max(1, threads); if (nt > n / 8192 + 1) nt = n / 8192 + 1; return (int)std::max<size_t>(1, nt); }
+
 // width + backtracking kernels over n reads of one length that are already packed on the device
 static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases, const uint32_t *d_nmask,
                        uint32_t pool_cap, int aln_cap, AlnRec *alns, int32_t *n_aln, uint8_t *status)
@@ -566,22 +585,36 @@ void batch_search(Batch &b)
     if (patched) PS_HIP(hipMemcpyAsync(b.d_class.p, b.h_class, (size_t)N, hipMemcpyHostToDevice, s));
     b.sub.clear(); b.n_class1 = 0; b.n_hard = 0;
     {
-        int64_t e = 0, h = 0;
-        std::vector<std::vector<int32_t>> want(b.bins.size());
-        for (int64_t g = 0; g < N; ++g) {
-            const uint8_t c = b.h_class[g];
-            if (c & PS_CLS_HOST) {
-                SubRead sr; sr.g = g; sr.cls = c & 3; sr.easy_before = e; sr.hard_before = h;
-                b.sub.push_back(std::move(sr));
-                const Bin &bin = b.bins[b.read_bin[g]];
-                if (bin.overflow.empty() || !bin.overflow.count(b.read_local[g])) want[b.read_bin[g]].push_back(b.read_local[g]);
+        // pass 1: per range, the number of class-1 / class-2 reads and of reads the host finishes
+        const int nt = par_threads((size_t)N, ctx->host_threads);
+        std::vector<int64_t> ce(nt + 1, 0), ch(nt + 1, 0), cs(nt + 1, 0);
+        par_for((size_t)N, ctx->host_threads, [&](size_t g0, size_t g1, int t) {
+            int64_t e = 0, h = 0, sn = 0;
+            for (size_t g = g0; g < g1; ++g) { const uint8_t c = b.h_class[g]; e += (c & 3) == 1; h += (c & 3) == 2; sn += (c & PS_CLS_HOST) != 0; }
+            ce[t + 1] = e; ch[t + 1] = h; cs[t + 1] = sn;
+        });
+        for (int t = 0; t < nt; ++t) { ce[t + 1] += ce[t]; ch[t + 1] += ch[t]; cs[t + 1] += cs[t]; }
+        b.n_class1 = ce[nt]; b.n_hard = ch[nt];
+        b.sub.resize((size_t)cs[nt]);
+        // pass 2: the subset with its position in the tie-break stream
+        par_for((size_t)N, ctx->host_threads, [&](size_t g0, size_t g1, int t) {
+            int64_t e = ce[t], h = ch[t]; size_t q = (size_t)cs[t];
+            for (size_t g = g0; g < g1; ++g) {
+                const uint8_t c = b.h_class[g];
+                if (c & PS_CLS_HOST) { SubRead &sr = b.sub[q++]; sr = SubRead(); sr.g = (int64_t)g; sr.cls = c & 3; sr.easy_before = e; sr.hard_before = h; }
+                e += (c & 3) == 1; h += (c & 3) == 2;
             }
-            e += (c & 3) == 1; h += (c & 3) == 2;
+        });
+        // hit lists of the subset: gathered on the device in subset order, one pinned download per bin
+        std::vector<std::vector<int32_t>> want(b.bins.size());
+        std::vector<int32_t> slot(b.sub.size(), -1);
+        for (size_t q = 0; q < b.sub.size(); ++q) {
+            const SubRead &sr = b.sub[q];
+            const int bi = b.read_bin[sr.g]; const Bin &bin = b.bins[bi];
+            if (bin.overflow.empty() || !bin.overflow.count(b.read_local[sr.g])) { slot[q] = (int32_t)want[bi].size(); want[bi].push_back(b.read_local[sr.g]); }
         }
-        b.n_class1 = e; b.n_hard = h;
-        // hit lists of the subset: gathered on the device, one small download per bin
-        std::vector<size_t> cursor(b.bins.size(), 0);
-        std::vector<std::vector<AlnRec>> got(b.bins.size()); std::vector<std::vector<int32_t>> got_n(b.bins.size());
+        b.sub_alns.resize(b.bins.size());
+        std::vector<const AlnRec *> got(b.bins.size(), nullptr); std::vector<const int32_t *> got_n(b.bins.size(), nullptr);
         for (size_t bi = 0; bi < b.bins.size(); ++bi) {
             const int m = (int)want[bi].size();
             if (!m) continue;
@@ -590,20 +623,22 @@ void batch_search(Batch &b)
             int32_t *d_no = ctx->ws_get<int32_t>("sub_n", m);
             PS_HIP(hipMemcpyAsync(d_loc, want[bi].data(), (size_t)m * 4, hipMemcpyHostToDevice, s));
             hipLaunchKernelGGL(k_gather_sub, dim3((m + 255) / 256), dim3(256), 0, s, bin.d_alns.p, bin.aln_cap, bin.d_n_aln.p, d_loc, m, d_out, d_no);
-            got[bi].resize((size_t)m * bin.aln_cap); got_n[bi].resize(m);
-            PS_HIP(hipMemcpyAsync(got[bi].data(), d_out, got[bi].size() * sizeof(AlnRec), hipMemcpyDeviceToHost, s));
-            PS_HIP(hipMemcpyAsync(got_n[bi].data(), d_no, (size_t)m * 4, hipMemcpyDeviceToHost, s));
-            PS_HIP(hipStreamSynchronize(s));
+            if (!b.sub_alns[bi]) b.sub_alns[bi].reset(new PinBuf());
+            const size_t bytes_al = (size_t)m * bin.aln_cap * sizeof(AlnRec);
+            uint8_t *hp = (uint8_t *)b.sub_alns[bi]->get(bytes_al + (size_t)m * 4 + 64);
+            PS_HIP(hipMemcpyAsync(hp, d_out, bytes_al, hipMemcpyDeviceToHost, s));
+            PS_HIP(hipMemcpyAsync(hp + bytes_al, d_no, (size_t)m * 4, hipMemcpyDeviceToHost, s));
+            got[bi] = reinterpret_cast<const AlnRec *>(hp); got_n[bi] = reinterpret_cast<const int32_t *>(hp + bytes_al);
         }
-        for (SubRead &sr : b.sub) {
-            const int bi = b.read_bin[sr.g]; Bin &bin = b.bins[bi];
-            auto it = bin.overflow.empty() ? bin.overflow.end() : bin.overflow.find(b.read_local[sr.g]);
-            if (it != bin.overflow.end()) sr.alns = it->second;
-            else {
-                const size_t q = cursor[bi]++;
-                sr.alns.assign(got[bi].begin() + q * bin.aln_cap, got[bi].begin() + q * bin.aln_cap + got_n[bi][q]);
+        PS_HIP(hipStreamSynchronize(s));
+        par_for(b.sub.size(), ctx->host_threads, [&](size_t q0, size_t q1, int) {
+            for (size_t q = q0; q < q1; ++q) {
+                SubRead &sr = b.sub[q];
+                const int bi = b.read_bin[sr.g]; Bin &bin = b.bins[bi];
+                if (slot[q] < 0) { const std::vector<AlnRec> &v = bin.overflow.find(b.read_local[sr.g])->second; sr.alns = v.data(); sr.n_alns = (int32_t)v.size(); }
+                else { sr.alns = got[bi] + (size_t)slot[q] * bin.aln_cap; sr.n_alns = got_n[bi][slot[q]]; }
             }
-        }
+        });
     }
     b.tm.ms_classify = ms_since(tcl);
     b.searched = true; b.selected_hard = b.selected = b.located = false;
@@ -674,7 +709,7 @@ void batch_select_hard(Batch &b, uint64_t draws_before, uint64_t *draws_after)
         rng.jump(2ull * (uint64_t)(sr.easy_before - e_prev));      // the single-best reads in between took two draws each
         e_prev = sr.easy_before;
         sr.hit = Hit();
-        H += (uint64_t)choose_main(sr.alns.data(), (int)sr.alns.size(), rng, sr.hit);
+        H += (uint64_t)choose_main(sr.alns, sr.n_alns, rng, sr.hit);
         b.hard_draws_cum[(size_t)sr.hard_before] = H;
     }
     b.draws_out = draws_before + 2ull * (uint64_t)b.n_class1 + H;
@@ -715,31 +750,52 @@ void batch_select_easy(Batch &b, int threads)
     // ---- host: the subset (its class-1 members by the same offset algebra, then the alternative-hit lists) ----
     const int n_occ = ctx->opt.n_occ;
     b.multis.clear();
-    for (SubRead &sr : b.sub) {
-        const int na = (int)sr.alns.size();
-        Hit &h = sr.hit;
-        if (sr.cls == 0 || na == 0) { h = Hit(); h.type = 0; h.pos = -1; continue; }
-        if (sr.cls == 1) {
-            h = Hit();
-            Rng48 rng(11);
-            rng.jump(b.draws_in + 2ull * (uint64_t)sr.easy_before + (sr.hard_before ? b.hard_draws_cum[(size_t)sr.hard_before - 1] : 0ull));
-            Rng48 probe = rng;
-            if (probe.step() == 0) throw Error("tie-break stream hit the zero state; sequential replay required");
-            choose_main(sr.alns.data(), na, rng, h);
-        }
-        h.pos = -1; h.multi_begin = (int32_t)b.multis.size(); h.n_multi = 0;
-        if (n_occ > 0) {                     // alternative hits (samse -n): only if all occurrences of all hits number <= n_occ+1
-            int tot = 0;
-            for (int k = 0; k < na; ++k) tot += (int)((uint64_t)(sr.alns[k].l - sr.alns[k].k) + 1ull);
-            if (tot >= 0 && tot <= n_occ + 1)
-                for (int k = 0; k < na; ++k)
-                    for (uint64_t row = sr.alns[k].k; row <= sr.alns[k].l; ++row) {
-                        Multi m; std::memset(&m, 0, sizeof m);
-                        m.row = (bwtint)row; m.gap = sr.alns[k].n_gapo + sr.alns[k].n_gape; m.mm = sr.alns[k].n_mm;
-                        m.ref_shift = (int)sr.alns[k].n_del - (int)sr.alns[k].n_ins; m.pos = -1;
-                        b.multis.push_back(m); ++h.n_multi;
-                    }
-        }
+    {
+        const int nt = par_threads(b.sub.size(), threads);
+        std::vector<std::vector<Multi>> part(nt);
+        std::vector<size_t> first(nt + 1, 0);
+        par_for(b.sub.size(), threads, [&](size_t q0, size_t q1, int t) {
+            std::vector<Multi> &mine = part[t];
+            first[t] = q0;
+            for (size_t q = q0; q < q1; ++q) {
+                SubRead &sr = b.sub[q];
+                const int na = sr.n_alns;
+                Hit &h = sr.hit;
+                if (sr.cls == 0 || na == 0) { h = Hit(); h.type = 0; h.pos = -1; continue; }
+                if (sr.cls == 1) {
+                    h = Hit();
+                    Rng48 rng(11);
+                    rng.jump(b.draws_in + 2ull * (uint64_t)sr.easy_before + (sr.hard_before ? b.hard_draws_cum[(size_t)sr.hard_before - 1] : 0ull));
+                    Rng48 probe = rng;
+                    if (probe.step() == 0) throw Error("tie-break stream hit the zero state; sequential replay required");
+                    choose_main(sr.alns, na, rng, h);
+                }
+                h.pos = -1; h.multi_begin = (int32_t)mine.size(); h.n_multi = 0;     // local index: shifted below
+                if (n_occ > 0) {                     // alternative hits (samse -n): only if all occurrences of all hits number <= n_occ+1
+                    int tot = 0;
+                    for (int k = 0; k < na; ++k) tot += (int)((uint64_t)(sr.alns[k].l - sr.alns[k].k) + 1ull);
+                    if (tot >= 0 && tot <= n_occ + 1)
+                        for (int k = 0; k < na; ++k)
+                            for (uint64_t row = sr.alns[k].k; row <= sr.alns[k].l; ++row) {
+                                Multi m; std::memset(&m, 0, sizeof m);
+                                m.row = (bwtint)row; m.gap = sr.alns[k].n_gapo + sr.alns[k].n_gape; m.mm = sr.alns[k].n_mm;
+                                m.ref_shift = (int)sr.alns[k].n_del - (int)sr.alns[k].n_ins; m.pos = -1;
+                                mine.push_back(m); ++h.n_multi;
+                            }
+                }
+            }
+        });
+        std::vector<size_t> base(nt + 1, 0);
+        for (int t = 0; t < nt; ++t) base[t + 1] = base[t] + part[t].size();
+        b.multis.resize(base[nt]);
+        const size_t per = b.sub.empty() ? 1 : (b.sub.size() + (size_t)nt - 1) / (size_t)nt;
+        par_for((size_t)nt, nt, [&](size_t t0, size_t t1, int) {
+            for (size_t t = t0; t < t1; ++t) {
+                if (!part[t].empty()) std::memcpy(b.multis.data() + base[t], part[t].data(), part[t].size() * sizeof(Multi));
+                const size_t q0 = t * per, q1 = std::min(b.sub.size(), q0 + per);
+                for (size_t q = q0; q < q1; ++q) if (b.sub[q].cls != 0 && b.sub[q].n_alns != 0) b.sub[q].hit.multi_begin += (int32_t)base[t];
+            }
+        });
     }
     int err = 0;
     PS_HIP(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, s));
@@ -866,8 +922,8 @@ void batch_locate(Batch &b)
     const size_t M = b.sub.size(), n_rows = M + b.multis.size();
     if (n_rows) {
         std::vector<bwtint> rows(n_rows), pos(n_rows);
-        for (size_t q = 0; q < M; ++q) rows[q] = b.sub[q].hit.type != 0 ? b.sub[q].hit.sa : 0;
-        for (size_t j = 0; j < b.multis.size(); ++j) rows[M + j] = b.multis[j].row;
+        par_for(M, ctx->host_threads, [&](size_t q0, size_t q1, int) { for (size_t q = q0; q < q1; ++q) rows[q] = b.sub[q].hit.type != 0 ? b.sub[q].hit.sa : 0; });
+        par_for(b.multis.size(), ctx->host_threads, [&](size_t j0, size_t j1, int) { for (size_t j = j0; j < j1; ++j) rows[M + j] = b.multis[j].row; });
         bwtint *d_r = ctx->ws_get<bwtint>("sub_rows", n_rows), *d_p = ctx->ws_get<bwtint>("sub_pos", n_rows);
         PS_HIP(hipMemcpyAsync(d_r, rows.data(), n_rows * sizeof(bwtint), hipMemcpyHostToDevice, s));
         { EvTimer t(s); launch_sa2pos(ctx->ix.view, d_r, d_p, (int)n_rows, nullptr, s); PS_HIP(hipGetLastError()); b.tm.ms_sa2pos += t.stop(); }
@@ -876,30 +932,42 @@ void batch_locate(Batch &b)
         std::vector<std::vector<RefineItem>> items(b.bins.size());
         struct Back { size_t q; int32_t multi; };             // multi < 0: main hit
         std::vector<std::vector<Back>> back(b.bins.size());
-        for (size_t q = 0; q < M; ++q) {
-            SubRead &sr = b.sub[q]; Hit &h = sr.hit;
-            const int len = b.rs.len[sr.g], bi = b.read_bin[sr.g];
-            if (h.type != 0) {
-                int strand = 0;
-                h.pos = to_forward(pos[q], l_pac, len + h.ref_shift, strand);
-                h.strand = strand;
-                h.mapq = approx_mapq(h, ctx->opt, len);
-                if (h.pos < 0) h.type = 0;
-            }
-            int kept = 0;
-            for (int j = 0; j < h.n_multi; ++j) {
-                Multi &m = b.multis[h.multi_begin + j];
-                int strand = 0;
-                m.pos = to_forward(pos[M + h.multi_begin + j], l_pac, len + m.ref_shift, strand);
-                m.strand = strand;
-                if (m.pos != h.pos && m.pos >= 0) b.multis[h.multi_begin + kept++] = m;
-            }
-            h.n_multi = kept;
-            for (int j = 0; j < h.n_multi; ++j) {
-                Multi &m = b.multis[h.multi_begin + j];
-                if (m.gap) { items[bi].push_back(RefineItem{b.read_local[sr.g], (bwtint)m.pos, m.ref_shift, m.strand}); back[bi].push_back(Back{q, j}); }
-            }
-            if (h.type != 0 && h.n_gapo) { items[bi].push_back(RefineItem{b.read_local[sr.g], (bwtint)h.pos, h.ref_shift, h.strand}); back[bi].push_back(Back{q, -1}); }
+        {
+            const int nt = par_threads(M, ctx->host_threads);
+            std::vector<std::vector<std::vector<RefineItem>>> t_items(nt, std::vector<std::vector<RefineItem>>(b.bins.size()));
+            std::vector<std::vector<std::vector<Back>>> t_back(nt, std::vector<std::vector<Back>>(b.bins.size()));
+            par_for(M, ctx->host_threads, [&](size_t q0, size_t q1, int t) {
+                for (size_t q = q0; q < q1; ++q) {
+                    SubRead &sr = b.sub[q]; Hit &h = sr.hit;
+                    const int len = b.rs.len[sr.g], bi = b.read_bin[sr.g];
+                    if (h.type != 0) {
+                        int strand = 0;
+                        h.pos = to_forward(pos[q], l_pac, len + h.ref_shift, strand);
+                        h.strand = strand;
+                        h.mapq = approx_mapq(h, ctx->opt, len);
+                        if (h.pos < 0) h.type = 0;
+                    }
+                    int kept = 0;
+                    for (int j = 0; j < h.n_multi; ++j) {
+                        Multi &m = b.multis[h.multi_begin + j];
+                        int strand = 0;
+                        m.pos = to_forward(pos[M + h.multi_begin + j], l_pac, len + m.ref_shift, strand);
+                        m.strand = strand;
+                        if (m.pos != h.pos && m.pos >= 0) b.multis[h.multi_begin + kept++] = m;
+                    }
+                    h.n_multi = kept;
+                    for (int j = 0; j < h.n_multi; ++j) {
+                        Multi &m = b.multis[h.multi_begin + j];
+                        if (m.gap) { t_items[t][bi].push_back(RefineItem{b.read_local[sr.g], (bwtint)m.pos, m.ref_shift, m.strand}); t_back[t][bi].push_back(Back{q, j}); }
+                    }
+                    if (h.type != 0 && h.n_gapo) { t_items[t][bi].push_back(RefineItem{b.read_local[sr.g], (bwtint)h.pos, h.ref_shift, h.strand}); t_back[t][bi].push_back(Back{q, -1}); }
+                }
+            });
+            for (int t = 0; t < nt; ++t)
+                for (size_t bi = 0; bi < b.bins.size(); ++bi) {
+                    items[bi].insert(items[bi].end(), t_items[t][bi].begin(), t_items[t][bi].end());
+                    back[bi].insert(back[bi].end(), t_back[t][bi].begin(), t_back[t][bi].end());
+                }
         }
         for (size_t bi = 0; bi < b.bins.size(); ++bi) {
             const int n_it = (int)items[bi].size();
@@ -928,16 +996,18 @@ void batch_locate(Batch &b)
                 }
             }
         }
-        for (SubRead &sr : b.sub) {          // alternatives whose gapped refinement produced nothing are dropped
-            Hit &h = sr.hit;
-            int kept = 0;
-            for (int j = 0; j < h.n_multi; ++j) {
-                Multi &m = b.multis[h.multi_begin + j];
-                if (m.gap && m.n_cigar == 0) continue;
-                b.multis[h.multi_begin + kept++] = m;
+        par_for(M, ctx->host_threads, [&](size_t q0, size_t q1, int) {          // alternatives whose gapped refinement produced nothing are dropped
+            for (size_t q = q0; q < q1; ++q) {
+                Hit &h = b.sub[q].hit;
+                int kept = 0;
+                for (int j = 0; j < h.n_multi; ++j) {
+                    Multi &m = b.multis[h.multi_begin + j];
+                    if (m.gap && m.n_cigar == 0) continue;
+                    b.multis[h.multi_begin + kept++] = m;
+                }
+                h.n_multi = kept;
             }
-            h.n_multi = kept;
-        }
+        });
     }
     b.tm.ms_host_post += ms_since(t1);
     b.located = true;
