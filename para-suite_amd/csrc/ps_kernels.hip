@@ -130,6 +130,7 @@ __global__ void __launch_bounds__(256) k_backtrack(const BtArgs *__restrict__ ap
     // executed by the whole wave.
     const int lane = threadIdx.x & 63;
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    const unsigned long long t_start = wall_clock64();
     int q_next = 0, q_end = 0;
     bool exhausted = false;
     for (;;) {
@@ -194,6 +195,9 @@ __global__ void __launch_bounds__(256) k_backtrack(const BtArgs *__restrict__ ap
         }
         bt_iter<WIDE>(a, h, L, m, fetch_r, serve_hit);
     }
+    // how long this wave was busy (160 ns units, summed over waves in the otherwise unused lf field): the mean wave
+    // time against the kernel time is the share of the launch spent waiting for the last long reads
+    if (lane == 0) L.st.lf = (uint32_t)((wall_clock64() - t_start) >> 4);
     flush_stats(a.stats, L.st);
 }
 

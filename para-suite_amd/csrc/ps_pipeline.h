@@ -48,9 +48,28 @@ struct PinBuf {                     // page-locked host staging (D2H at PCIe rat
     void *get(size_t need) { if (need > bytes) { if (p) (void)hipHostFree(p); p = nullptr; bytes = 0; PS_HIP(hipHostMalloc(&p, need, hipHostMallocDefault)); bytes = need; } return p; }
 };
 
+// One lane of work on the device: a stream with its own grow-only device workspace and pinned staging (hipMalloc /
+// hipFree of GBs per call is slow).  A context has two, so that two batches can be in flight -- one batch's kernel tail
+// and host-side stages overlap with the other's search kernel.
+struct Work {
+    hipStream_t stream = nullptr;
+    std::map<std::string, DevBuf<uint8_t>> ws; std::map<std::string, PinBuf> pin;
+    template <class T> T *ws_get(const std::string &name, size_t count) {
+        DevBuf<uint8_t> &b = ws[name];
+        const size_t need = count * sizeof(T);
+        if (b.n < need) b.alloc(need + need / 8);
+        return reinterpret_cast<T *>(b.p);
+    }
+    template <class T> T *pin_get(const std::string &name, size_t count) { return reinterpret_cast<T *>(pin[name].get(count * sizeof(T) + 64)); }
+    Work() {}
+    Work(const Work &) = delete;
+    Work &operator=(const Work &) = delete;
+    ~Work() { if (stream) (void)hipStreamDestroy(stream); }
+};
+
 struct Ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;    // index build / load
     Index ix;
     Options opt;
     int bt_blocks = 0;             // grid of the backtracking kernel (0 = 4 blocks per CU)
@@ -60,15 +79,10 @@ struct Ctx {
     int n_big = 4096;              // 1 MB stack slots a launch may hand to reads that outgrow their private slice
     int fetch_min = 8, hit_min = 1;    // batching hits costs more in idle lanes than it saves (measured)
     int host_threads = 8;
-    // grow-only device workspace and pinned staging, reused by every search (hipMalloc/hipFree of GBs per call is slow)
-    std::map<std::string, DevBuf<uint8_t>> ws; std::map<std::string, PinBuf> pin;
-    template <class T> T *ws_get(const std::string &name, size_t count) {
-        DevBuf<uint8_t> &b = ws[name];
-        const size_t need = count * sizeof(T);
-        if (b.n < need) b.alloc(need + need / 8);
-        return reinterpret_cast<T *>(b.p);
-    }
-    template <class T> T *pin_get(const std::string &name, size_t count) { return reinterpret_cast<T *>(pin[name].get(count * sizeof(T) + 64)); }             // idle lanes a wave collects before it loads new reads
+    static const int N_WORK = 2;
+    std::unique_ptr<Work> work[N_WORK];
+    int next_work = 0;             // batches take the lanes in turn
+    Work *take_work();             // creates the lane's stream on first use
     ~Ctx();
 };
 
@@ -87,6 +101,7 @@ struct Bin {
 
 struct Batch {
     Ctx *ctx = nullptr;
+    Work *wk = nullptr;            // the lane of work this batch runs on
     ReadSet rs;
     std::vector<Bin> bins;
     std::vector<int32_t> read_bin, read_local;

@@ -35,6 +35,12 @@ void require_device(int device)
 }
 
 Ctx::~Ctx() { if (stream) (void)hipStreamDestroy(stream); }
+Work *Ctx::take_work()
+{
+    const int w = next_work; next_work = (next_work + 1) % N_WORK;
+    if (!work[w]) { work[w].reset(new Work()); PS_HIP(hipStreamCreateWithFlags(&work[w]->stream, hipStreamNonBlocking)); }
+    return work[w].get();
+}
 
 // ------------------------------------------------------------- read input ----
 static inline uint8_t code_of(int ch)
@@ -183,6 +189,8 @@ std::unique_ptr<Batch> batch_create(Ctx *ctx, ReadSet &&rs_in)
 {
     std::unique_ptr<Batch> b(new Batch());
     b->ctx = ctx; b->rs = std::move(rs_in);
+    b->wk = ctx->take_work();
+    Work *wk = b->wk;
     const ReadSet &rs = b->rs;
     std::map<int, int> bin_of_len;
     b->read_bin.resize((size_t)rs.n); b->read_local.resize((size_t)rs.n);
@@ -239,13 +247,13 @@ std::unique_ptr<Batch> batch_create(Ctx *ctx, ReadSet &&rs_in)
             pack(0);
             for (auto &x : th) x.join();
         }
-        bin.d_ids.alloc(n); bin.d_ids.upload(bin.ids.data(), n, ctx->stream);
+        bin.d_ids.alloc(n); bin.d_ids.upload(bin.ids.data(), n, wk->stream);
         bin.bases.alloc(bin.h_bases.size()); bin.nmask.alloc(bin.h_nmask.size());
-        bin.bases.upload(bin.h_bases.data(), bin.h_bases.size(), ctx->stream);
-        bin.nmask.upload(bin.h_nmask.data(), bin.h_nmask.size(), ctx->stream);
+        bin.bases.upload(bin.h_bases.data(), bin.h_bases.size(), wk->stream);
+        bin.nmask.upload(bin.h_nmask.data(), bin.h_nmask.size(), wk->stream);
     }
     b->d_stats.alloc(3);
-    PS_HIP(hipStreamSynchronize(ctx->stream));
+    PS_HIP(hipStreamSynchronize(wk->stream));
     return b;
 }
 
@@ -293,11 +301,11 @@ static int par_threads(size_t n, int threads) { size_t nt = (size_t)std::max(1, 
 static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases, const uint32_t *d_nmask,
                        uint32_t pool_cap, int aln_cap, AlnRec *alns, int32_t *n_aln, uint8_t *status)
 {
-    Ctx *ctx = b.ctx; hipStream_t s = ctx->stream;
+    Ctx *ctx = b.ctx; Work *wk = b.wk; hipStream_t s = wk->stream;
     const int len = md.len, seed_len = md.seed_len;
-    uint32_t *w = ctx->ws_get<uint32_t>("w", (size_t)(len + 1) * n);
-    uint32_t *cwb = ctx->ws_get<uint32_t>("cwb", (size_t)lm_ncw(len) * n);
-    uint32_t *cswb = ctx->ws_get<uint32_t>("cswb", (size_t)(lm_ncsw(seed_len) + 1) * n);
+    uint32_t *w = wk->ws_get<uint32_t>("w", (size_t)(len + 1) * n);
+    uint32_t *cwb = wk->ws_get<uint32_t>("cwb", (size_t)lm_ncw(len) * n);
+    uint32_t *cswb = wk->ws_get<uint32_t>("cswb", (size_t)(lm_ncsw(seed_len) + 1) * n);
     WidthArgs wa;
     wa.ix = ctx->ix.view; wa.n_reads = n; wa.len = len; wa.seed_len = seed_len; wa.use_seed = md.use_seed;
     wa.bases = d_bases; wa.nmask = d_nmask; wa.w = w; wa.cwb = cwb; wa.cswb = cswb; wa.stats = b.d_stats.p + 0;
@@ -317,9 +325,9 @@ static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases
     const size_t max_lanes = ((size_t)(wide ? 32 : 64) << 30) / per_lane;
     if ((size_t)blocks * 256 > max_lanes) blocks = (int)std::max<size_t>(1, max_lanes / 256);
     const int n_lanes = blocks * 256;
-    uint8_t *pool = ctx->ws_get<uint8_t>("pool", (size_t)n_lanes * pool_cap * (wide ? sizeof(Entry) : 16));
-    uint32_t *heads = wide ? ctx->ws_get<uint32_t>("heads", (size_t)n_lanes * PS_MAX_BUCKETS) : nullptr;
-    uint32_t *queue = ctx->ws_get<uint32_t>("queue", 16);
+    uint8_t *pool = wk->ws_get<uint8_t>("pool", (size_t)n_lanes * pool_cap * (wide ? sizeof(Entry) : 16));
+    uint32_t *heads = wide ? wk->ws_get<uint32_t>("heads", (size_t)n_lanes * PS_MAX_BUCKETS) : nullptr;
+    uint32_t *queue = wk->ws_get<uint32_t>("queue", 16);
     PS_HIP(hipMemsetAsync(queue, 0, 64, s));
     BtArgs a; std::memset(&a, 0, sizeof a);
     a.ix = ctx->ix.view; a.md = md; a.n_reads = n; a.len = len; a.n_lanes = n_lanes;
@@ -330,15 +338,15 @@ static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases
     a.queue = queue; a.fetch_min = ctx->fetch_min; a.hit_min = ctx->hit_min;
     if (!wide && pool_cap < 65535 && ctx->n_big > 0) {         // large slots for the reads that outgrow their private slice
         a.big_cap = 65535; a.n_big = (uint32_t)std::min<int64_t>(ctx->n_big, std::max(64, n));
-        a.big_pool = ctx->ws_get<uint8_t>("big_pool", (size_t)a.n_big * a.big_cap * 16);
+        a.big_pool = wk->ws_get<uint8_t>("big_pool", (size_t)a.n_big * a.big_cap * 16);
         a.big_next = queue + 4;                                  // second counter in the zeroed queue words
-        a.big_busy = ctx->ws_get<uint32_t>("big_busy", a.n_big);
+        a.big_busy = wk->ws_get<uint32_t>("big_busy", a.n_big);
         PS_HIP(hipMemsetAsync(a.big_busy, 0, (size_t)a.n_big * 4, s));
     }
     uint32_t *riters = nullptr;
-    if (ctx->want_read_iters) { riters = ctx->ws_get<uint32_t>("riters", n); PS_HIP(hipMemsetAsync(riters, 0, (size_t)n * 4, s)); a.read_iters = riters; }
+    if (ctx->want_read_iters) { riters = wk->ws_get<uint32_t>("riters", n); PS_HIP(hipMemsetAsync(riters, 0, (size_t)n * 4, s)); a.read_iters = riters; }
     { EvTimer t(s);
-      if (!launch_backtrack(a, ctx->ws_get<BtArgs>("btargs", 1), blocks, lm, s)) throw Error("cost model outside the ranges the search kernel packs (gap/score fields must fit a byte)");
+      if (!launch_backtrack(a, wk->ws_get<BtArgs>("btargs", 1), blocks, lm, s)) throw Error("cost model outside the ranges the search kernel packs (gap/score fields must fit a byte)");
       PS_HIP(hipGetLastError());
       const double ms = t.stop(); b.tm.ms_backtrack += ms; ++b.tm.n_backtrack_launches;
       if (std::getenv("PS_VERBOSE")) std::fprintf(stderr, "[parasuite-hip]   backtrack launch: %d reads x %d bp, stack %u%s, %d lanes, %.1f ms\n", n, len, pool_cap, wide ? " (wide)" : "", n_lanes, ms); }
@@ -347,17 +355,17 @@ static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases
 
 // ------------------------------------------------------------- host helpers ------
 // download the hit lists of n reads (stride aln_cap on the device) in compact form
-static void download_alns(Ctx *ctx, int n, int aln_cap, const AlnRec *d_alns, const int32_t *d_n_aln,
+static void download_alns(Work *wk, int n, int aln_cap, const AlnRec *d_alns, const int32_t *d_n_aln,
                           std::vector<int32_t> &n_aln, std::vector<uint32_t> &off, std::vector<AlnRec> &alns)
 {
-    hipStream_t s = ctx->stream;
-    uint32_t *cnt = ctx->ws_get<uint32_t>("cnt", n), *d_off = ctx->ws_get<uint32_t>("off", (size_t)n + 1);
+    hipStream_t s = wk->stream;
+    uint32_t *cnt = wk->ws_get<uint32_t>("cnt", n), *d_off = wk->ws_get<uint32_t>("off", (size_t)n + 1);
     hipLaunchKernelGGL(k_clip_counts, dim3((n + 255) / 256), dim3(256), 0, s, d_n_aln, aln_cap, n, cnt);
     size_t tb = 0;
     PS_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, cnt, d_off, n, s));
-    uint8_t *tmp = ctx->ws_get<uint8_t>("scan_tmp", tb ? tb : 1);
+    uint8_t *tmp = wk->ws_get<uint8_t>("scan_tmp", tb ? tb : 1);
     PS_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tb, cnt, d_off, n, s));
-    int32_t *p_na = ctx->pin_get<int32_t>("dl_n_aln", n); uint32_t *p_off = ctx->pin_get<uint32_t>("dl_off", (size_t)n + 1);
+    int32_t *p_na = wk->pin_get<int32_t>("dl_n_aln", n); uint32_t *p_off = wk->pin_get<uint32_t>("dl_off", (size_t)n + 1);
     PS_HIP(hipMemcpyAsync(p_na, d_n_aln, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     PS_HIP(hipMemcpyAsync(p_off, d_off, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     PS_HIP(hipStreamSynchronize(s));
@@ -366,9 +374,9 @@ static void download_alns(Ctx *ctx, int n, int aln_cap, const AlnRec *d_alns, co
     p_off[n] = last;
     n_aln.assign(p_na, p_na + n); off.assign(p_off, p_off + n + 1); alns.resize(last);
     if (last) {
-        AlnRec *comp = ctx->ws_get<AlnRec>("comp", last);
+        AlnRec *comp = wk->ws_get<AlnRec>("comp", last);
         hipLaunchKernelGGL(k_gather_alns, dim3((n + 255) / 256), dim3(256), 0, s, d_alns, aln_cap, d_n_aln, d_off, n, comp);
-        AlnRec *p_al = ctx->pin_get<AlnRec>("dl_alns", last);
+        AlnRec *p_al = wk->pin_get<AlnRec>("dl_alns", last);
         PS_HIP(hipMemcpyAsync(p_al, comp, (size_t)last * sizeof(AlnRec), hipMemcpyDeviceToHost, s));
         PS_HIP(hipStreamSynchronize(s));
         std::memcpy(alns.data(), p_al, (size_t)last * sizeof(AlnRec));
@@ -513,7 +521,7 @@ __global__ void k_post(PostArgs a)
 // --------------------------------------------------------------- search stage -------
 void batch_search(Batch &b)
 {
-    Ctx *ctx = b.ctx; hipStream_t s = ctx->stream;
+    Ctx *ctx = b.ctx; Work *wk = b.wk; hipStream_t s = wk->stream;
     require_device(ctx->device);
     b.tm = Timing();
     auto t0 = Clock::now();
@@ -527,7 +535,7 @@ void batch_search(Batch &b)
         if (bin.d_alns.n < (size_t)n * ctx->aln_cap[0]) { bin.d_alns.alloc((size_t)n * ctx->aln_cap[0]); bin.d_n_aln.alloc(n); bin.d_status.alloc(n); }
         bin.aln_cap = ctx->aln_cap[0];
         run_search(b, bin.md, n, bin.bases.p, bin.nmask.p, ctx->pool_cap[0], bin.aln_cap, bin.d_alns.p, bin.d_n_aln.p, bin.d_status.p);
-        uint8_t *h_status = ctx->pin_get<uint8_t>("status", n);
+        uint8_t *h_status = wk->pin_get<uint8_t>("status", n);
         PS_HIP(hipMemcpyAsync(h_status, bin.d_status.p, (size_t)n, hipMemcpyDeviceToHost, s));
         hipLaunchKernelGGL(k_classify, dim3(std::min((n + 255) / 256, 4096)), dim3(256), 0, s, bin.d_alns.p, bin.aln_cap, bin.d_n_aln.p, bin.d_status.p,
                            bin.d_ids.p, n, ctx->opt.n_occ, b.d_class.p);
@@ -554,7 +562,7 @@ void batch_search(Batch &b)
             run_search(b, bin.md, m, db.p, dm.p, ctx->pool_cap[tier], ctx->aln_cap[tier], ta.p, tn.p, ts.p);
             std::vector<uint8_t> st(m); ts.download(st.data(), m, s);
             std::vector<int32_t> na; std::vector<uint32_t> off; std::vector<AlnRec> al;
-            download_alns(ctx, m, ctx->aln_cap[tier], ta.p, tn.p, na, off, al);
+            download_alns(wk, m, ctx->aln_cap[tier], ta.p, tn.p, na, off, al);
             std::vector<int32_t> still;
             for (int q = 0; q < m; ++q) {
                 if (st[q] == RS_BAD_SCORE) throw Error("internal: score outside the bucket range");
@@ -619,8 +627,8 @@ void batch_search(Batch &b)
             const int m = (int)want[bi].size();
             if (!m) continue;
             Bin &bin = b.bins[bi];
-            int32_t *d_loc = ctx->ws_get<int32_t>("sub_local", m); AlnRec *d_out = ctx->ws_get<AlnRec>("sub_alns", (size_t)m * bin.aln_cap);
-            int32_t *d_no = ctx->ws_get<int32_t>("sub_n", m);
+            int32_t *d_loc = wk->ws_get<int32_t>("sub_local", m); AlnRec *d_out = wk->ws_get<AlnRec>("sub_alns", (size_t)m * bin.aln_cap);
+            int32_t *d_no = wk->ws_get<int32_t>("sub_n", m);
             PS_HIP(hipMemcpyAsync(d_loc, want[bi].data(), (size_t)m * 4, hipMemcpyHostToDevice, s));
             hipLaunchKernelGGL(k_gather_sub, dim3((m + 255) / 256), dim3(256), 0, s, bin.d_alns.p, bin.aln_cap, bin.d_n_aln.p, d_loc, m, d_out, d_no);
             if (!b.sub_alns[bi]) b.sub_alns[bi].reset(new PinBuf());
@@ -649,7 +657,7 @@ void Batch::ensure_host_alns()
 {
     for (Bin &bin : bins) {
         if (bin.host_alns_valid) continue;
-        download_alns(ctx, (int)bin.ids.size(), bin.aln_cap, bin.d_alns.p, bin.d_n_aln.p, bin.h_n_aln, bin.h_off, bin.h_alns);
+        download_alns(wk, (int)bin.ids.size(), bin.aln_cap, bin.d_alns.p, bin.d_n_aln.p, bin.h_n_aln, bin.h_off, bin.h_alns);
         for (auto &kv : bin.overflow) bin.h_n_aln[kv.first] = (int32_t)kv.second.size();
         bin.host_alns_valid = true;
     }
@@ -721,24 +729,24 @@ void batch_select_hard(Batch &b, uint64_t draws_before, uint64_t *draws_after)
 void batch_select_easy(Batch &b, int threads)
 {
     if (!b.selected_hard) throw Error("select_easy before select_hard");
-    Ctx *ctx = b.ctx; hipStream_t s = ctx->stream;
+    Ctx *ctx = b.ctx; Work *wk = b.wk; hipStream_t s = wk->stream;
     auto t0 = Clock::now();
     const int64_t N = b.rs.n;
     (void)threads;
     // ---- device: prefix counts of the two draw classes, then every single-best read picks its occurrence ----
     if (b.d_sel.n < (size_t)N) { b.d_sel.alloc((size_t)N); b.d_fin.alloc((size_t)N); b.d_rows.alloc((size_t)N + 1); b.d_pos.alloc((size_t)N + 1); b.d_eb.alloc((size_t)N); b.d_hb.alloc((size_t)N); }
     {
-        uint32_t *f1 = ctx->ws_get<uint32_t>("flag1", (size_t)N), *f2 = ctx->ws_get<uint32_t>("flag2", (size_t)N);
+        uint32_t *f1 = wk->ws_get<uint32_t>("flag1", (size_t)N), *f2 = wk->ws_get<uint32_t>("flag2", (size_t)N);
         hipLaunchKernelGGL(k_class_flags, dim3(2048), dim3(256), 0, s, b.d_class.p, (long long)N, f1, f2);
         size_t tb = 0;
         PS_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, f1, b.d_eb.p, (size_t)N, s));
-        uint8_t *tmp = ctx->ws_get<uint8_t>("scan_tmp", tb ? tb : 1);
+        uint8_t *tmp = wk->ws_get<uint8_t>("scan_tmp", tb ? tb : 1);
         PS_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tb, f1, b.d_eb.p, (size_t)N, s));
         PS_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tb, f2, b.d_hb.p, (size_t)N, s));
     }
-    unsigned long long *d_cum = ctx->ws_get<unsigned long long>("hard_cum", (size_t)b.n_hard + 1);
+    unsigned long long *d_cum = wk->ws_get<unsigned long long>("hard_cum", (size_t)b.n_hard + 1);
     if (b.n_hard) PS_HIP(hipMemcpyAsync(d_cum, b.hard_draws_cum.data(), (size_t)b.n_hard * 8, hipMemcpyHostToDevice, s));
-    int *d_err = ctx->ws_get<int>("sel_err", 4);
+    int *d_err = wk->ws_get<int>("sel_err", 4);
     PS_HIP(hipMemsetAsync(d_err, 0, 16, s));
     for (Bin &bin : b.bins) {
         SelectArgs a;
@@ -846,15 +854,15 @@ static int fix_cigar(uint32_t *cigar, int n, int64_t &rb)
 // banded DP kernel over a list of items of one length bin; cigars come back to the host
 static void run_refine(Batch &b, Bin &bin, const RefineItem *d_items, int n_it, std::vector<uint32_t> &cig, std::vector<int32_t> &nc)
 {
-    Ctx *ctx = b.ctx; hipStream_t s = ctx->stream;
-    uint32_t *d_cig = ctx->ws_get<uint32_t>("rf_cig", (size_t)n_it * PS_MAX_CIGAR); int32_t *d_nc = ctx->ws_get<int32_t>("rf_nc", n_it);
+    Ctx *ctx = b.ctx; Work *wk = b.wk; hipStream_t s = wk->stream;
+    uint32_t *d_cig = wk->ws_get<uint32_t>("rf_cig", (size_t)n_it * PS_MAX_CIGAR); int32_t *d_nc = wk->ws_get<int32_t>("rf_nc", n_it);
     int blocks = (n_it + 63) / 64; if (blocks > 2048) blocks = 2048;
     const int tmax = bin.len + 64;
     RefineArgs ra;
     ra.ix = ctx->ix.view; ra.n_items = n_it; ra.len = bin.len; ra.n_reads = (int)bin.ids.size();
     ra.bases = bin.bases.p; ra.nmask = bin.nmask.p; ra.items = d_items; ra.cigar = d_cig; ra.n_cigar = d_nc;
     ra.z_per_block = (size_t)64 * tmax * (bin.len < 2 * tmax + 1 ? bin.len : 2 * tmax + 1);
-    ra.zbuf = ctx->ws_get<uint8_t>("rf_z", ra.z_per_block * blocks);
+    ra.zbuf = wk->ws_get<uint8_t>("rf_z", ra.z_per_block * blocks);
     { EvTimer t(s); launch_refine(ra, blocks, s); PS_HIP(hipGetLastError()); b.tm.ms_refine += t.stop(); }
     cig.resize((size_t)n_it * PS_MAX_CIGAR); nc.resize(n_it);
     PS_HIP(hipMemcpyAsync(cig.data(), d_cig, cig.size() * 4, hipMemcpyDeviceToHost, s));
@@ -865,7 +873,7 @@ static void run_refine(Batch &b, Bin &bin, const RefineItem *d_items, int n_it, 
 void batch_locate(Batch &b)
 {
     if (!b.selected) throw Error("locate before select");
-    Ctx *ctx = b.ctx; hipStream_t s = ctx->stream;
+    Ctx *ctx = b.ctx; Work *wk = b.wk; hipStream_t s = wk->stream;
     require_device(ctx->device);
     const int64_t N = b.rs.n, l_pac = ctx->ix.ref.l_pac;
     auto t0 = Clock::now();
@@ -873,7 +881,7 @@ void batch_locate(Batch &b)
     { EvTimer t(s); launch_sa2pos(ctx->ix.view, b.d_rows.p, b.d_pos.p, (int)N, b.d_stats.p + 2, s); PS_HIP(hipGetLastError()); b.tm.ms_sa2pos += t.stop(); }
     uint8_t logn[256]; logn[0] = 0;
     for (int n = 1; n < 256; ++n) logn[n] = (uint8_t)mapq_logn(n);
-    uint8_t *d_logn = ctx->ws_get<uint8_t>("logn", 256);
+    uint8_t *d_logn = wk->ws_get<uint8_t>("logn", 256);
     PS_HIP(hipMemcpyAsync(d_logn, logn, 256, hipMemcpyHostToDevice, s));
     b.dev_cigars.clear();
     struct BinItems { RefineItem *d_items; int32_t *d_item_g; unsigned int *d_n; unsigned int n; };
@@ -882,8 +890,8 @@ void batch_locate(Batch &b)
         Bin &bin = b.bins[bi];
         const int n = (int)bin.ids.size();
         BinItems &it = bi_items[bi];
-        it.d_items = ctx->ws_get<RefineItem>("post_items" + std::to_string(bi), n); it.d_item_g = ctx->ws_get<int32_t>("post_item_g" + std::to_string(bi), n);
-        it.d_n = ctx->ws_get<unsigned int>("post_n" + std::to_string(bi), 4);
+        it.d_items = wk->ws_get<RefineItem>("post_items" + std::to_string(bi), n); it.d_item_g = wk->ws_get<int32_t>("post_item_g" + std::to_string(bi), n);
+        it.d_n = wk->ws_get<unsigned int>("post_n" + std::to_string(bi), 4);
         PS_HIP(hipMemsetAsync(it.d_n, 0, 16, s));
         PostArgs a;
         a.ids = bin.d_ids.p; a.n = n; a.len = bin.len; a.l_pac = l_pac; a.cls = b.d_class.p; a.sel = b.d_sel.p; a.pos = b.d_pos.p; a.fin = b.d_fin.p;
@@ -924,7 +932,7 @@ void batch_locate(Batch &b)
         std::vector<bwtint> rows(n_rows), pos(n_rows);
         par_for(M, ctx->host_threads, [&](size_t q0, size_t q1, int) { for (size_t q = q0; q < q1; ++q) rows[q] = b.sub[q].hit.type != 0 ? b.sub[q].hit.sa : 0; });
         par_for(b.multis.size(), ctx->host_threads, [&](size_t j0, size_t j1, int) { for (size_t j = j0; j < j1; ++j) rows[M + j] = b.multis[j].row; });
-        bwtint *d_r = ctx->ws_get<bwtint>("sub_rows", n_rows), *d_p = ctx->ws_get<bwtint>("sub_pos", n_rows);
+        bwtint *d_r = wk->ws_get<bwtint>("sub_rows", n_rows), *d_p = wk->ws_get<bwtint>("sub_pos", n_rows);
         PS_HIP(hipMemcpyAsync(d_r, rows.data(), n_rows * sizeof(bwtint), hipMemcpyHostToDevice, s));
         { EvTimer t(s); launch_sa2pos(ctx->ix.view, d_r, d_p, (int)n_rows, nullptr, s); PS_HIP(hipGetLastError()); b.tm.ms_sa2pos += t.stop(); }
         PS_HIP(hipMemcpyAsync(pos.data(), d_p, n_rows * sizeof(bwtint), hipMemcpyDeviceToHost, s));
@@ -972,7 +980,7 @@ void batch_locate(Batch &b)
         for (size_t bi = 0; bi < b.bins.size(); ++bi) {
             const int n_it = (int)items[bi].size();
             if (!n_it) continue;
-            RefineItem *d_it = ctx->ws_get<RefineItem>("sub_items", n_it);
+            RefineItem *d_it = wk->ws_get<RefineItem>("sub_items", n_it);
             PS_HIP(hipMemcpyAsync(d_it, items[bi].data(), (size_t)n_it * sizeof(RefineItem), hipMemcpyHostToDevice, s));
             std::vector<uint32_t> cig; std::vector<int32_t> nc;
             run_refine(b, b.bins[bi], d_it, n_it, cig, nc);

@@ -113,13 +113,23 @@ def test_profile_sam_bit_exact(ctx_example, example, workdir, x):
     _compare(ctx_example, example["orc_index"], orc.profile_opt(P, 2.1e-5, 5.9e-4, x), fq, workdir, "prof_%d" % x)
 
 
-def test_mixed_lengths_and_contig_edges(ctx_multi, multi, workdir):
-    """ragged input (36-75 bp, length-binned on the device), multi contig, repeats, N runs"""
+@pytest.mark.parametrize("mode", ["stock", "profile"])
+def test_mixed_lengths_and_contig_edges(ctx_multi, multi, workdir, mode):
+    """ragged input (36-75 bp, length-binned on the device: BASELINE configs[4] in small), multi contig, repeats, N runs;
+    stock costs and the error + indel profile"""
     import orc
+    import simulate as S
     fq = _fastq(multi["genome"], workdir, "mixed", n_reads=2500, read_len=75, min_len=36, seed=13, indel_scale=40,
                 n_frac=0.003)
-    ctx_multi.set_stock("0.04")
-    _compare(ctx_multi, multi["orc_index"], orc.stock_opt("0.04"), fq, workdir, "mixed")
+    if mode == "stock":
+        ctx_multi.set_stock("0.04")
+        opt = orc.stock_opt("0.04")
+    else:
+        P = S.EXAMPLE_PROFILE.copy()
+        P[3, 1], P[3, 3] = 0.12, 0.87
+        ctx_multi.set_profile(P, 2.1e-5, 5.9e-4, -1)
+        opt = orc.profile_opt(P, 2.1e-5, 5.9e-4, -1)
+    _compare(ctx_multi, multi["orc_index"], opt, fq, workdir, "mixed_" + mode)
 
 
 def test_small_tiers_escalate(ctx_example, example, workdir):
