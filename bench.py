@@ -328,9 +328,6 @@ def main():
                                                             "ms_refine", "ms_host_post", "ms_classify", "ms_rows", "ms_sel_hard", "ms_sel_easy")},
             "stage_wall_ms_per_step": {k: 1e3 * v / K for k, v in wall.items()},
             "kstats": {"backtrack": ks_bt, "width": ks_w, "sa2pos": ks_sa},
-            # share of the dominant launch the average wave was busy (the rest is waiting for the last long reads)
-            "wave_busy_frac": (ks_bt["lf_steps"] * 16 / 1e5 / max(1, (acc["ms_backtrack"] / max(1, acc["n_backtrack_launches"])))
-                               / max(1.0, min(args.reads, 262144) / 64.0)),
             "mapped_frac": float((hits["type"] != 0).mean()),
             "overflow_reads": [int(acc["n_overflow_tier1"] / K), int(acc["n_overflow_tier2"] / K)],
         }
