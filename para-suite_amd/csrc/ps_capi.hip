@@ -1,6 +1,10 @@
 // ps_capi.hip -- extern "C" boundary (include/parasuite_hip.h).  Exceptions stop here.
 #include <hip/hip_runtime.h>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -20,6 +24,17 @@ struct ps_ctx { Ctx c; };
 struct ps_batch { std::unique_ptr<Batch> b; };
 
 static_assert(sizeof(ps_aln) == sizeof(AlnRec), "ps_aln layout");
+
+// bounded hand-over between the stages of ps_map
+namespace {
+template <class T> struct Chan {
+    std::mutex m; std::condition_variable cv; std::deque<T> q; bool closed = false; size_t cap = 2;
+    void push(T &&v) { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return q.size() < cap || closed; }); if (closed) return; q.push_back(std::move(v)); cv.notify_all(); }
+    bool pop(T &v) { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return !q.empty() || closed; }); if (q.empty()) return false; v = std::move(q.front()); q.pop_front(); cv.notify_all(); return true; }
+    void close() { std::lock_guard<std::mutex> l(m); closed = true; cv.notify_all(); }      // what is queued is still handed out
+    void abort() { std::lock_guard<std::mutex> l(m); closed = true; q.clear(); cv.notify_all(); }
+};
+}
 
 extern "C" {
 
@@ -269,46 +284,97 @@ int ps_batch_kstats(ps_batch *b, int which, ps_kstats *o)
     PS_CATCH_INT
 }
 
+// The whole `map` step behind one call.  Three stages run side by side on pieces of the input (whole records, about
+// PS_CHUNK_MB of FASTQ each, default 400): a parser thread, this thread driving the GPU (pack + upload, search, samse
+// stage; the tie-break stream position is carried from piece to piece), and a writer thread formatting SAM.  The
+// index is loaded while the parser already works.
 int ps_map(int threads, const char *mm, const char *error_profile, const char *indel_profile,
            const char *ref_fa, const char *fastq, const char *out_sam)
 {
     PS_TRY
         const bool verbose = std::getenv("PS_VERBOSE") != nullptr;
-        auto t0 = std::chrono::steady_clock::now();
-        auto lap = [&](const char *what) {
-            if (!verbose) return;
-            auto t1 = std::chrono::steady_clock::now();
-            std::fprintf(stderr, "[parasuite-hip] %-28s %.3f s\n", what, std::chrono::duration<double>(t1 - t0).count());
-            t0 = t1;
-        };
-        ps_ctx *x = index_files_exist(ref_fa) ? ps_ctx_open(ref_fa, 0) : ps_ctx_build(ref_fa, 0, 1);
-        if (!x) return 1;
-        lap("index resident");
-        int rc = error_profile && error_profile[0] ? ps_ctx_set_profile(x, error_profile, indel_profile, mm)
-                                                   : ps_ctx_set_stock(x, mm && mm[0] ? mm : "0.04");
-        x->c.host_threads = threads > 0 ? threads : 1;
-        ps_batch *b = nullptr;
-        if (!rc) {
+        const auto t_begin = std::chrono::steady_clock::now();
+        auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); };
+        const int nthr = threads > 0 ? threads : 1;
+        size_t chunk_bytes = (size_t)400 << 20;
+        if (const char *e = std::getenv("PS_CHUNK_MB")) chunk_bytes = (size_t)std::max(1, std::atoi(e)) << 20;
+        Chan<ReadSet> parsed; Chan<std::unique_ptr<Batch>> mapped;
+        std::exception_ptr perr, werr;
+        double t_parse = 0, t_write = 0;
+        // ---- stage 1: parser (starts at once; the file is read whole, then parsed piece by piece)
+        std::thread parser([&]() {
             try {
-                require_device(x->c.device);
-                ReadSet rs; load_reads(fastq, rs, x->c.host_threads);
-                lap("reads parsed");
-                b = new ps_batch();
-                b->b = batch_create(&x->c, std::move(rs));
-                lap("reads packed + uploaded");
-            } catch (const std::exception &e) { delete b; b = nullptr; rc = fail(e.what()); }
-        }
-        if (!rc) rc = ps_batch_run(b, threads);
-        if (!rc) lap("mapped (GPU stages)");
-        if (!rc && verbose) {
-            const Timing &t = b->b->tm;
-            std::fprintf(stderr, "[parasuite-hip]   of which: width %.0f backtrack %.0f classify %.0f rows %.0f select %.0f+%.0f sa2pos %.0f refine %.0f host_post %.0f ms; launches %d\n",
-                         t.ms_width, t.ms_backtrack, t.ms_classify, t.ms_rows, t.ms_sel_hard, t.ms_sel_easy, t.ms_sa2pos, t.ms_refine, t.ms_host_post, t.n_backtrack_launches);
-        }
-        if (!rc) rc = ps_batch_write_sam(b, out_sam, 1, threads);
-        if (!rc) lap("SAM written");
-        ps_batch_free(b); ps_ctx_close(x);
-        return rc;
+                load_reads_chunked(fastq, std::max(1, nthr / 2), chunk_bytes, [&](ReadSet &&rs) {
+                    const auto t0 = std::chrono::steady_clock::now();
+                    parsed.push(std::move(rs));
+                    (void)t0;
+                });
+                t_parse = since();
+            } catch (...) { perr = std::current_exception(); }
+            parsed.close();
+        });
+        // ---- stage 3: writer
+        std::thread writer([&]() {
+            try {
+                std::unique_ptr<Batch> b; bool first = true;
+                while (mapped.pop(b)) {
+                    const auto t0 = std::chrono::steady_clock::now();
+                    batch_write_sam(*b, out_sam, first, "@PG\tID:parasuite-hip\tPN:parasuite-hip\tVN:0.1", nthr, !first);   // the parser is done by now; the GPU stage needs its threads only in bursts
+                    t_write += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                    first = false; b.reset();
+                }
+                if (first) {                      // no reads at all: header only
+                    FILE *f = std::fopen(out_sam, "wb");
+                    if (!f) throw Error(std::string("cannot write ") + out_sam);
+                    std::fclose(f);
+                }
+            } catch (...) { werr = std::current_exception(); mapped.abort(); }
+        });
+        // ---- stage 2: this thread
+        int rc = 0; std::string msg;
+        ps_ctx *x = nullptr;
+        double t_index = 0, t_gpu = 0; int64_t n_reads = 0; int n_pieces = 0;
+        try {
+            x = index_files_exist(ref_fa) ? ps_ctx_open(ref_fa, 0) : ps_ctx_build(ref_fa, 0, 1);
+            if (!x) throw Error(g_err);
+            t_index = since();
+            if (error_profile && error_profile[0] ? ps_ctx_set_profile(x, error_profile, indel_profile, mm)
+                                                   : ps_ctx_set_stock(x, mm && mm[0] ? mm : "0.04")) throw Error(g_err);
+            x->c.host_threads = nthr;
+            require_device(x->c.device);
+            uint64_t draws = 0;
+            ReadSet rs;
+            bool header_only = true;
+            while (parsed.pop(rs)) {
+                const auto t0 = std::chrono::steady_clock::now();
+                n_reads += rs.n; ++n_pieces;
+                std::unique_ptr<Batch> b = batch_create(&x->c, std::move(rs));
+                batch_search(*b);
+                batch_select_hard(*b, draws, &draws);
+                batch_select_easy(*b, nthr);
+                batch_locate(*b);
+                if (verbose) {
+                    const Timing &t = b->tm;
+                    std::fprintf(stderr, "[parasuite-hip]   piece %d: %lld reads; width %.0f backtrack %.0f classify %.0f select %.0f+%.0f sa2pos %.0f refine %.0f host_post %.0f ms\n",
+                                 n_pieces, (long long)b->rs.n, t.ms_width, t.ms_backtrack, t.ms_classify, t.ms_sel_hard, t.ms_sel_easy, t.ms_sa2pos, t.ms_refine, t.ms_host_post);
+                }
+                t_gpu += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                header_only = false;
+                mapped.push(std::move(b));
+                if (werr) break;
+            }
+            (void)header_only;
+        } catch (const std::exception &e) { rc = 1; msg = e.what(); parsed.abort(); }
+        mapped.close();
+        parser.join(); writer.join();
+        if (!rc && perr) { try { std::rethrow_exception(perr); } catch (const std::exception &e) { rc = 1; msg = e.what(); } }
+        if (!rc && werr) { try { std::rethrow_exception(werr); } catch (const std::exception &e) { rc = 1; msg = e.what(); } }
+        if (x) ps_ctx_close(x);
+        if (rc) return fail(msg);
+        if (verbose)
+            std::fprintf(stderr, "[parasuite-hip] ps_map: %lld reads in %d piece(s), %.3f s; index resident after %.3f s, parser done after %.3f s, "
+                                 "GPU stage busy %.3f s, SAM writer busy %.3f s\n", (long long)n_reads, n_pieces, since(), t_index, t_parse, t_gpu, t_write);
+        return 0;
     PS_CATCH_INT
 }
 

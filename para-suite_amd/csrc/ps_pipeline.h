@@ -1,5 +1,6 @@
 // ps_pipeline.h -- batch pipeline behind the C ABI (host orchestration of the gfx950 kernels).
 #pragma once
+#include <functional>
 #include <map>
 #include <memory>
 #include "ps_host.h"
@@ -16,6 +17,7 @@ struct ReadSet {
     const char *name(int64_t i, size_t &l) const { l = (size_t)(name_off[i + 1] - name_off[i]); return names.data() + name_off[i]; }
 };
 void load_reads(const char *path, ReadSet &rs, int threads = 1); // FASTQ or FASTA
+void load_reads_chunked(const char *path, int threads, size_t chunk_bytes, const std::function<void(ReadSet &&)> &sink);
 void reads_from_codes(int64_t n, int len, const uint8_t *codes, ReadSet &rs);
 
 static const int PS_HIT_CIGAR = 8;
@@ -81,7 +83,7 @@ struct Ctx {
     int host_threads = 8;
     static const int N_WORK = 2;
     std::unique_ptr<Work> work[N_WORK];
-    int next_work = 0;             // batches take the lanes in turn
+    int n_work = 1, next_work = 0; // lanes in use (1: every batch shares one workspace and stream); batches take them in turn
     Work *take_work();             // creates the lane's stream on first use
     ~Ctx();
 };
@@ -128,6 +130,6 @@ void batch_search(Batch &b);                                    // width + backt
 void batch_select_hard(Batch &b, uint64_t draws_before, uint64_t *draws_after);
 void batch_select_easy(Batch &b, int threads);
 void batch_locate(Batch &b);                                    // SA walk kernel, strand / MAPQ, banded DP of gapped hits
-void batch_write_sam(Batch &b, const char *path, bool header, const char *pg_line, int threads);
+void batch_write_sam(Batch &b, const char *path, bool header, const char *pg_line, int threads, bool append = false);
 
 }  // namespace ps

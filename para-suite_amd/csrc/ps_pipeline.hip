@@ -16,6 +16,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <thread>
 #include "ps_pipeline.h"
 #include "ps_core.h"
@@ -37,7 +38,7 @@ void require_device(int device)
 Ctx::~Ctx() { if (stream) (void)hipStreamDestroy(stream); }
 Work *Ctx::take_work()
 {
-    const int w = next_work; next_work = (next_work + 1) % N_WORK;
+    const int w = next_work; next_work = (next_work + 1) % std::max(1, std::min(n_work, (int)N_WORK));
     if (!work[w]) { work[w].reset(new Work()); PS_HIP(hipStreamCreateWithFlags(&work[w]->stream, hipStreamNonBlocking)); }
     return work[w].get();
 }
@@ -105,23 +106,15 @@ static void parse_reads_range(const char *buf, size_t i0, size_t i1, ReadSet &rs
 
 // FASTQ / FASTA; read name = header up to the first white space, a trailing /1 or /2 removed.  Four-line FASTQ is
 // cut at record boundaries (a line starting with '@' whose second next line starts with '+') and parsed by `threads`.
-void load_reads(const char *path, ReadSet &rs, int threads)
+// record starts that split [a, b) of the file image into `parts` pieces (FASTQ only; anything else stays whole)
+static std::vector<size_t> cut_records(const char *b, size_t lo, size_t hi, int parts)
 {
-    FILE *f = std::fopen(path, "rb");
-    if (!f) throw Error(std::string("cannot open reads ") + path);
-    std::fseek(f, 0, SEEK_END); long sz = std::ftell(f); std::fseek(f, 0, SEEK_SET);
-    std::vector<char> buf((size_t)sz + 1);
-    if (sz && std::fread(buf.data(), 1, (size_t)sz, f) != (size_t)sz) { std::fclose(f); throw Error(std::string("short read on ") + path); }
-    std::fclose(f);
-    const size_t n = (size_t)sz;
-    const char *b = buf.data();
-    if (threads < 1) threads = 1;
-    if (threads > 64) threads = 64;
-    std::vector<size_t> cut(1, 0);
-    if (threads > 1 && n > (size_t)(1 << 20) && b[0] == '@') {
+    std::vector<size_t> cut(1, lo);
+    const size_t n = hi;
+    if (parts > 1 && hi - lo > (size_t)(1 << 20) && b[lo] == '@') {
         auto next_line = [&](size_t i) { const char *e = (const char *)std::memchr(b + i, '\n', n - i); return e ? (size_t)(e - b) + 1 : n; };
-        for (int t = 1; t < threads; ++t) {
-            size_t i = next_line(n / threads * t);
+        for (int t = 1; t < parts; ++t) {
+            size_t i = next_line(lo + (hi - lo) / (size_t)parts * (size_t)t);
             for (int tries = 0; tries < 8 && i < n; ++tries) {          // first line here that really starts a record
                 const size_t l1 = next_line(i), l2 = l1 < n ? next_line(l1) : n;
                 if (b[i] == '@' && l2 < n && b[l2] == '+') break;
@@ -130,7 +123,15 @@ void load_reads(const char *path, ReadSet &rs, int threads)
             if (i < n && i > cut.back()) cut.push_back(i);
         }
     }
-    cut.push_back(n);
+    cut.push_back(hi);
+    return cut;
+}
+// parse [lo, hi) of the file image on `threads` threads
+static void parse_span(const char *b, size_t lo, size_t hi, int threads, ReadSet &rs)
+{
+    if (threads < 1) threads = 1;
+    if (threads > 64) threads = 64;
+    const std::vector<size_t> cut = cut_records(b, lo, hi, threads);
     const int parts = (int)cut.size() - 1;
     std::vector<ReadSet> piece((size_t)parts);
     std::vector<char> anyq((size_t)parts, 0);
@@ -164,6 +165,38 @@ void load_reads(const char *path, ReadSet &rs, int threads)
         r = ReadSet();
     }
     rs.has_qual = any_qual;
+}
+static void read_file(const char *path, std::vector<char> &buf)
+{
+    FILE *f = std::fopen(path, "rb");
+    if (!f) throw Error(std::string("cannot open reads ") + path);
+    std::fseek(f, 0, SEEK_END); long sz = std::ftell(f); std::fseek(f, 0, SEEK_SET);
+    buf.resize((size_t)sz + 1);
+    if (sz && std::fread(buf.data(), 1, (size_t)sz, f) != (size_t)sz) { std::fclose(f); throw Error(std::string("short read on ") + path); }
+    std::fclose(f);
+    buf[(size_t)sz] = 0;
+}
+
+void load_reads(const char *path, ReadSet &rs, int threads)
+{
+    std::vector<char> buf;
+    read_file(path, buf);
+    parse_span(buf.data(), 0, buf.size() - 1, threads, rs);
+}
+
+// the same input in pieces of about chunk_bytes (whole records), in order: sink(piece) may block
+void load_reads_chunked(const char *path, int threads, size_t chunk_bytes, const std::function<void(ReadSet &&)> &sink)
+{
+    std::vector<char> buf;
+    read_file(path, buf);
+    const size_t n = buf.size() - 1;
+    const int parts = (int)std::max<size_t>(1, (n + chunk_bytes - 1) / std::max<size_t>(1, chunk_bytes));
+    const std::vector<size_t> cut = cut_records(buf.data(), 0, n, parts);
+    for (size_t c = 0; c + 1 < cut.size(); ++c) {
+        ReadSet rs;
+        parse_span(buf.data(), cut[c], cut[c + 1], threads, rs);
+        sink(std::move(rs));
+    }
 }
 
 void reads_from_codes(int64_t n, int len, const uint8_t *codes, ReadSet &rs)
@@ -1090,11 +1123,15 @@ static void sam_line(const Batch &b, int64_t g, std::string &o)
     size_t nl; const char *nm_ = rs.name(g, nl);
     o.append(nm_, nl);
     auto put_seq = [&](int strand) {
-        if (!strand) for (int i = 0; i < len; ++i) o.push_back("ACGTN"[seq[i]]);
-        else for (int i = len - 1; i >= 0; --i) o.push_back("TGCAN"[seq[i]]);
-        o.push_back('\t');
-        if (qual) { if (!strand) o.append(qual, (size_t)len); else for (int i = len - 1; i >= 0; --i) o.push_back(qual[i]); }
-        else o.push_back('*');
+        const size_t at = o.size();
+        o.resize(at + (size_t)len + 1 + (qual ? (size_t)len : 1));
+        char *d = &o[at];
+        if (!strand) for (int i = 0; i < len; ++i) d[i] = "ACGTN"[seq[i]];
+        else for (int i = 0; i < len; ++i) d[i] = "TGCAN"[seq[len - 1 - i]];
+        d[len] = '\t';
+        d += len + 1;
+        if (qual) { if (!strand) std::memcpy(d, qual, (size_t)len); else for (int i = 0; i < len; ++i) d[i] = qual[len - 1 - i]; }
+        else d[0] = '*';
     };
     if (h.type == 0) { o.append("\t4\t*\t0\t0\t*\t*\t0\t0\t"); put_seq(h.strand); o.push_back('\n'); return; }
     int seqid = 0, flag = 0;
@@ -1109,10 +1146,12 @@ static void sam_line(const Batch &b, int64_t g, std::string &o)
     o.append("\t*\t0\t0\t");
     put_seq(h.strand);
     // oriented read for MD/NM
-    std::vector<uint8_t> tmp;
+    uint8_t tmp_small[256]; std::vector<uint8_t> tmp_big;
+    uint8_t *tmp = tmp_small;
+    if (len > 256) { tmp_big.resize((size_t)len); tmp = tmp_big.data(); }
     const uint8_t *oriented = seq;
-    if (h.strand) { tmp.resize((size_t)len); for (int i = 0; i < len; ++i) { uint8_t c = seq[len - 1 - i]; tmp[i] = c > 3 ? c : (uint8_t)(3 - c); } oriented = tmp.data(); }
-    std::string md; int nm = 0;
+    if (h.strand) { for (int i = 0; i < len; ++i) { uint8_t c = seq[len - 1 - i]; tmp[i] = c > 3 ? c : (uint8_t)(3 - c); } oriented = tmp; }
+    static thread_local std::string md; md.clear(); int nm = 0;
     cal_md(ref, h.n_cigar, h.cigar, len, h.pos, oriented, md, nm);
     char XT = "NURM"[h.type];
     if (nn > 10) XT = 'N';
@@ -1137,10 +1176,10 @@ static void sam_line(const Batch &b, int64_t g, std::string &o)
     o.push_back('\n');
 }
 
-void batch_write_sam(Batch &b, const char *path, bool header, const char *pg_line, int threads)
+void batch_write_sam(Batch &b, const char *path, bool header, const char *pg_line, int threads, bool append)
 {
     if (!b.located) throw Error("write_sam before locate");
-    FILE *f = std::fopen(path, "wb");
+    FILE *f = std::fopen(path, append ? "ab" : "wb");
     if (!f) throw Error(std::string("cannot write ") + path);
     if (header) {
         for (const Contig &c : b.ctx->ix.ref.contigs) std::fprintf(f, "@SQ\tSN:%s\tLN:%d\n", c.name.c_str(), c.len);
@@ -1149,12 +1188,17 @@ void batch_write_sam(Batch &b, const char *path, bool header, const char *pg_lin
     const int64_t N = b.rs.n;
     if (threads < 1) threads = 1;
     if (threads > 64) threads = 64;
+    // rounds of threads x 64k reads: the text of a round is written by one I/O thread while the next round is formatted
     const int64_t chunk = 1 << 16;
-    for (int64_t base = 0; base < N; base += chunk * threads) {
-        std::vector<std::string> out((size_t)threads);
+    std::vector<std::string> bufs[2] = {std::vector<std::string>((size_t)threads), std::vector<std::string>((size_t)threads)};
+    std::thread io; bool io_ok = true;
+    int which = 0;
+    for (int64_t base = 0; base < N; base += chunk * threads, which ^= 1) {
+        std::vector<std::string> &out = bufs[which];          // the I/O thread may still hold the other set
         auto work = [&](int t) {
             int64_t g0 = base + chunk * t, g1 = std::min(N, g0 + chunk);
             std::string &o = out[t];
+            o.clear();
             if (g0 < g1) o.reserve((size_t)(g1 - g0) * 256);
             for (int64_t g = g0; g < g1; ++g) sam_line(b, g, o);
         };
@@ -1162,8 +1206,14 @@ void batch_write_sam(Batch &b, const char *path, bool header, const char *pg_lin
         for (int t = 1; t < threads; ++t) th.emplace_back(work, t);
         work(0);
         for (auto &x : th) x.join();
-        for (auto &o : out) if (!o.empty() && std::fwrite(o.data(), 1, o.size(), f) != o.size()) { std::fclose(f); throw Error(std::string("short write on ") + path); }
+        if (io.joinable()) io.join();
+        if (!io_ok) break;
+        io = std::thread([&out, f, &io_ok]() {
+            for (auto &o : out) if (!o.empty() && std::fwrite(o.data(), 1, o.size(), f) != o.size()) { io_ok = false; return; }
+        });
     }
+    if (io.joinable()) io.join();
+    if (!io_ok) { std::fclose(f); throw Error(std::string("short write on ") + path); }
     if (std::fclose(f) != 0) throw Error(std::string("cannot close ") + path);
 }
 

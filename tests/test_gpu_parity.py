@@ -216,3 +216,38 @@ def test_stack_growth_in_launch(ctx_example, example, workdir):
         assert b.timing()["n_overflow_tier1"] == 0
     finally:
         ctx_example.set_tiers(pool_cap=[16384, 65535, 2000064], aln_cap=[8, 256, 65536], bt_blocks=0)
+
+
+def test_ps_map_streams_in_pieces(mid, workdir, monkeypatch):
+    """ps_map cuts the input into pieces that a parser thread, the GPU stage and a SAM writer work on side by side; the
+    output must not depend on the cut (the tie-break stream is carried from piece to piece) and equals the oracle's."""
+    import capi
+    import orc
+    import simulate as S
+    sim = S.simulate_reads(mid["genome"], n_reads=40000, read_len=50, seed=77, indel_scale=30, n_frac=0.001)
+    fq = os.path.join(workdir, "stream.fq")
+    S.write_fastq(fq, sim)
+    assert os.path.getsize(fq) > 4 << 20
+    P = S.EXAMPLE_PROFILE.copy()
+    P[3, 1], P[3, 3] = 0.12, 0.87
+    ep, ip = os.path.join(workdir, "s.errorprofile"), os.path.join(workdir, "s.indelprofile")
+    with open(ep, "w") as f:
+        for row in P:
+            f.write("".join(repr(float(v)) + "\t" for v in row) + "\n")
+    open(ip, "w").write("2.1E-5\t5.9E-4")
+    fa = mid["fa"]
+    if not os.path.exists(fa + ".bwt"):
+        capi.ps_index(fa)
+    outs = []
+    for tag, mb in (("one", "4096"), ("many", "1")):
+        monkeypatch.setenv("PS_CHUNK_MB", mb)
+        out = os.path.join(workdir, "stream_%s.sam" % tag)
+        capi.ps_map(8, "-1", ep, ip, fa, fq, out)
+        outs.append(open(out, "rb").read())
+    assert outs[0] == outs[1]
+    osam = os.path.join(workdir, "stream.orc.sam")
+    mid["orc_index"].map_fastq(orc.profile_opt(P, 2.1e-5, 5.9e-4, -1), fq, osam, n_threads=8)
+    g, o = sam_records(os.path.join(workdir, "stream_many.sam")), sam_records(osam)
+    assert len(g) == len(o) == 40000
+    bad = [i for i in range(len(g)) if g[i] != o[i]]
+    assert not bad, (len(bad), g[bad[0]], o[bad[0]])
