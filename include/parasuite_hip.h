@@ -94,6 +94,15 @@ int     ps_batch_timing(ps_batch *, ps_timing *out);
 int64_t ps_ctx_read_iters(ps_ctx *, uint32_t *out, int64_t cap);   /* profiling aid (env PS_READ_ITERS=1): iterations per read of the last search launch */
 int     ps_batch_kstats(ps_batch *, int which /*0 width 1 backtrack 2 sa2pos*/, ps_kstats *out);
 
+/* ---- after the map step --------------------------------------------------------------
+ * One call for what PARAsuiteMapping.java:102-133 (`samtools view -bS -t ref x.sam -o x.bam`, `samtools view -q <mapq> -b`)
+ * and Mapping.java:85-108 (`samtools sort`, `samtools index`) spawn four processes for: SAM text -> BAM, records with
+ * MAPQ < min_mapq dropped, optionally sorted by coordinate (unplaced reads last, input order kept among equals) with
+ * <bam>.bai next to it.  Host code (zlib); needs no GPU. */
+typedef struct { uint64_t n_in, n_out, bam_bytes; } ps_bam_stats;
+int     ps_sam_to_bam(const char *sam, const char *bam, int min_mapq, int sort_by_coordinate, int write_index, int threads,
+                      ps_bam_stats *stats /* may be NULL */);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,7 +40,7 @@ HIT_DTYPE = np.dtype([("pos", "<i8"), ("sa", "<u8"), ("type", "<i4"), ("strand",
 
 EXPORTS = ["ps_version", "ps_last_error", "ps_index", "ps_map", "ps_ctx_open", "ps_ctx_build", "ps_ctx_close",
            "ps_ctx_set_stock", "ps_ctx_set_profile", "ps_ctx_set_profile_matrix", "ps_ctx_set_tiers", "ps_ctx_info",
-           "ps_ctx_blob", "ps_ctx_meta", "ps_ctx_from_blobs", "ps_ctx_fetch", "ps_ctx_export_blob", "ps_batch_from_fastq",
+           "ps_ctx_blob", "ps_ctx_meta", "ps_ctx_from_blobs", "ps_ctx_fetch", "ps_ctx_export_blob", "ps_sam_to_bam", "ps_batch_from_fastq",
            "ps_batch_from_codes", "ps_batch_free", "ps_batch_n", "ps_batch_search", "ps_batch_select_hard",
            "ps_batch_select_easy", "ps_batch_locate", "ps_batch_run", "ps_batch_write_sam", "ps_batch_n_aln",
            "ps_batch_alns", "ps_batch_hits", "ps_batch_timing", "ps_batch_kstats", "ps_ctx_read_iters"]
@@ -305,3 +305,17 @@ def ps_map(threads, mm, error_profile, indel_profile, ref_fa, fastq, out_sam):
     _chk(lib().ps_map(int(threads), str(mm).encode(), error_profile.encode() if error_profile else None,
                       indel_profile.encode() if indel_profile else None, ref_fa.encode(), fastq.encode(),
                       out_sam.encode()))
+
+
+class BamStats(C.Structure):
+    _fields_ = [("n_in", C.c_uint64), ("n_out", C.c_uint64), ("bam_bytes", C.c_uint64)]
+
+
+def ps_sam_to_bam(sam, bam, min_mapq=0, sort_by_coordinate=False, write_index=False, threads=8):
+    """SAM text -> BAM; MAPQ filter, coordinate sort and <bam>.bai in the same pass (host code, needs no GPU)."""
+    L = lib()
+    L.ps_sam_to_bam.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(BamStats)]
+    st = BamStats()
+    _chk(L.ps_sam_to_bam(sam.encode(), bam.encode(), int(min_mapq), int(bool(sort_by_coordinate)), int(bool(write_index)),
+                         int(threads), C.byref(st)))
+    return dict(n_in=st.n_in, n_out=st.n_out, bam_bytes=st.bam_bytes)

@@ -11,6 +11,7 @@
 #include <string>
 #include "../../include/parasuite_hip.h"
 #include "ps_pipeline.h"
+#include "ps_bam.h"
 
 using namespace ps;
 
@@ -374,6 +375,16 @@ int ps_map(int threads, const char *mm, const char *error_profile, const char *i
         if (verbose)
             std::fprintf(stderr, "[parasuite-hip] ps_map: %lld reads in %d piece(s), %.3f s; index resident after %.3f s, parser done after %.3f s, "
                                  "GPU stage busy %.3f s, SAM writer busy %.3f s\n", (long long)n_reads, n_pieces, since(), t_index, t_parse, t_gpu, t_write);
+        return 0;
+    PS_CATCH_INT
+}
+
+int ps_sam_to_bam(const char *sam, const char *bam, int min_mapq, int sort_by_coordinate, int write_index, int threads, ps_bam_stats *st)
+{
+    PS_TRY
+        BamStats s;
+        sam_to_bam(sam, bam, min_mapq, sort_by_coordinate != 0, write_index != 0, threads, &s);
+        if (st) { st->n_in = s.n_in; st->n_out = s.n_out; st->bam_bytes = s.bam_bytes; }
         return 0;
     PS_CATCH_INT
 }

@@ -6,9 +6,10 @@ Same names, argument meaning and error behaviour as
   PARAsuiteMapping (+ setErrorProfileFilename / setIndelProfileFilename)      (PARAsuiteMapping.java:22-154)
   BWAMapping                                                                    (BWAMapping.java:20-128)
 with the three `bwa` child processes replaced by calls into libparasuite_hip.so.  What the Java does
-after `bwa samse` -- samtools view -bS / view -q, rm, mv (PARAsuiteMapping.java:102-152) -- is BAM
-plumbing outside the hot path; here `<prefix>.sam` is left for it, and the MAPQ
-filter is offered on the SAM text so the output contract can be tested without samtools.
+after `bwa samse` -- samtools view -bS / view -q, rm, mv (PARAsuiteMapping.java:102-152), later samtools
+sort / index (Mapping.java:85-108) -- is offered as ONE library call, `samToFilteredBam` (SURVEY.md §8f rank 3,
+`ps_sam_to_bam`: BAM, MAPQ filter, coordinate sort and .bai without samtools); `<prefix>.sam` is left in place
+unless that method is called, and the MAPQ filter also exists on the SAM text.
 """
 import os
 import time
@@ -48,6 +49,14 @@ class Mapping:
             fn(*args)
         except capi.PsError as e:
             raise ExternalCallErrorException("%s: %s" % (what, e))
+
+    def samToFilteredBam(self, outputPrefix, mappingQualityFilter, sortByCoordinateAndIndex=False, threads=8):
+        """<prefix>.sam -> <prefix>.bam holding the reads with MAPQ >= filter (PARAsuiteMapping.java:102-152), optionally
+        coordinate-sorted with <prefix>.bam.bai (Mapping.sortByCoordinateAndIndex, Mapping.java:85-108); removes the SAM"""
+        self._call("samtools view -bS | view -q %d%s" % (mappingQualityFilter, " | sort | index" if sortByCoordinateAndIndex else ""),
+                   capi.ps_sam_to_bam, outputPrefix + ".sam", outputPrefix + ".bam", mappingQualityFilter,
+                   sortByCoordinateAndIndex, sortByCoordinateAndIndex, threads)
+        os.remove(outputPrefix + ".sam")
 
     @staticmethod
     def filter_sam_mapq(sam_in, sam_out, min_mapq):
