@@ -26,3 +26,6 @@ open('/tmp/e2e.indelprofile', 'w').write('2.1E-5\t5.9E-4')
 for rep in range(2):
     t = time.time(); os.environ['PS_VERBOSE']='1'; capi.ps_map(16, '-1', '/tmp/e2e.errorprofile', '/tmp/e2e.indelprofile', fa, fq, '/tmp/e2e.sam'); dt = time.time() - t
     print('ps_map (index load + %d reads + SAM written) %.2fs = %.2f M reads/s, SAM %.0f MB' % (n, dt, n / dt / 1e6, os.path.getsize('/tmp/e2e.sam') / 1e6), flush=True)
+for args in (dict(min_mapq=10), dict(min_mapq=10, sort_by_coordinate=True, write_index=True)):
+    t = time.time(); st = capi.ps_sam_to_bam('/tmp/e2e.sam', '/tmp/e2e.bam', threads=16, **args); dt = time.time() - t
+    print('ps_sam_to_bam %s: %.2fs, %d of %d records kept, BAM %.0f MB' % (args, dt, st['n_out'], st['n_in'], st['bam_bytes'] / 1e6), flush=True)
