@@ -7,9 +7,13 @@
 // genome needs ~70 GB of the 288 GB); there is no host suffix sorter.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
+#include <atomic>
 #include <cctype>
+#include <functional>
+#include <thread>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <sstream>
@@ -27,6 +31,9 @@ static inline int nt4(int c)
 
 // Non-ACGT characters become pseudo-random bases drawn from lrand48() seeded with 11 and are
 // recorded as holes (maximal runs of one identical character), as `bwa index` does.
+// A 3 GB FASTA is parsed on several threads: the bodies of the records are cut into pieces of whole lines,
+// a first pass counts bases and ambiguous characters per piece, prefix sums give every piece its place in
+// the pac, in its contig and in the lrand48 stream (jump-ahead), the second pass packs.
 void load_fasta(const char *path, RefSeq &ref)
 {
     FILE *f = std::fopen(path, "rb");
@@ -36,42 +43,112 @@ void load_fasta(const char *path, RefSeq &ref)
     if (sz && std::fread(buf.data(), 1, (size_t)sz, f) != (size_t)sz) { std::fclose(f); throw Error(std::string("short read on ") + path); }
     std::fclose(f);
     const size_t n = (size_t)sz;
-    Rng48 rng(11);
+    const char *b = buf.data();
     ref = RefSeq();
-    ref.pac.assign(n / 4 + 2, 0);
+    // ---- records: header fields and body spans
+    struct Span { size_t lo, hi; int contig; int64_t n_seq = 0, n_amb = 0, pos0 = 0, amb0 = 0; std::vector<Hole> holes; };
+    std::vector<Span> spans;
+    size_t PIECE = (size_t)8 << 20;
+    if (const char *e = std::getenv("PS_FASTA_PIECE")) PIECE = (size_t)std::max(1, std::atoi(e));     // tests: force many pieces
     size_t i = 0;
     while (i < n) {
-        while (i < n && buf[i] != '>') ++i;
+        while (i < n && b[i] != '>') ++i;
         if (i >= n) break;
         size_t s = ++i;
-        while (i < n && !std::isspace((unsigned char)buf[i])) ++i;
+        while (i < n && !std::isspace((unsigned char)b[i])) ++i;
         Contig c;
-        c.name.assign(buf.data() + s, i - s);
-        size_t e = i; while (e < n && buf[e] != '\n') ++e;
-        size_t cs = i; while (cs < e && std::isspace((unsigned char)buf[cs])) ++cs;
-        size_t ce = e; while (ce > cs && std::isspace((unsigned char)buf[ce - 1])) --ce;
-        c.anno = ce > cs ? std::string(buf.data() + cs, ce - cs) : std::string("(null)");
+        c.name.assign(b + s, i - s);
+        size_t e = i; while (e < n && b[e] != '\n') ++e;
+        size_t cs = i; while (cs < e && std::isspace((unsigned char)b[cs])) ++cs;
+        size_t ce = e; while (ce > cs && std::isspace((unsigned char)b[ce - 1])) --ce;
+        c.anno = ce > cs ? std::string(b + cs, ce - cs) : std::string("(null)");
+        c.offset = 0; c.len = 0; c.n_ambs = 0;
         i = e;
-        c.offset = ref.contigs.empty() ? 0 : ref.contigs.back().offset + ref.contigs.back().len;
-        c.n_ambs = 0;
-        int lasts = 0; int32_t pos = 0; bool open_hole = false;
-        for (; i < n && buf[i] != '>'; ++i) {
-            int ch = (unsigned char)buf[i];
+        const char *nx = i < n ? (const char *)std::memchr(b + i, '>', n - i) : nullptr;
+        const size_t body_end = nx ? (size_t)(nx - b) : n;
+        const int ci = (int)ref.contigs.size();
+        ref.contigs.push_back(c);
+        for (size_t lo = i; lo < body_end;) {                      // pieces end at a line end
+            size_t hi = std::min(body_end, lo + PIECE);
+            if (hi < body_end) { const char *nl = (const char *)std::memchr(b + hi, '\n', body_end - hi); hi = nl ? (size_t)(nl - b) + 1 : body_end; }
+            Span sp; sp.lo = lo; sp.hi = hi; sp.contig = ci;
+            spans.push_back(std::move(sp));
+            lo = hi;
+        }
+        i = body_end;
+    }
+    if (ref.contigs.empty()) throw Error(std::string("no sequences in ") + path);
+    int threads = (int)std::thread::hardware_concurrency();
+    if (threads < 1) threads = 1;
+    if (threads > 16) threads = 16;
+    auto run = [&](const std::function<void(Span &)> &fn) {
+        std::atomic<size_t> next(0);
+        std::vector<std::thread> th;
+        auto work = [&]() { for (size_t k; (k = next.fetch_add(1)) < spans.size();) fn(spans[k]); };
+        for (int t = 1; t < threads; ++t) th.emplace_back(work);
+        work();
+        for (auto &x : th) x.join();
+    };
+    // ---- pass 1: counts
+    run([&](Span &sp) {
+        int64_t ns = 0, na = 0;
+        for (size_t j = sp.lo; j < sp.hi; ++j) {
+            const int ch = (unsigned char)b[j];
+            if (!std::isgraph(ch)) continue;
+            ++ns; na += nt4(ch) >= 4;
+        }
+        sp.n_seq = ns; sp.n_amb = na;
+    });
+    int64_t l_pac = 0, amb = 0;
+    for (size_t k = 0; k < spans.size(); ++k) {
+        Span &sp = spans[k];
+        Contig &c = ref.contigs[(size_t)sp.contig];
+        if (k == 0 || spans[k - 1].contig != sp.contig) c.offset = l_pac;
+        // contigs without a body keep the running offset
+        sp.pos0 = l_pac; sp.amb0 = amb;
+        l_pac += sp.n_seq; amb += sp.n_amb;
+        if (c.len + sp.n_seq > 0x7fffffffLL) throw Error("a reference sequence is longer than 2^31-1 bases: " + c.name);
+        c.len += (int32_t)sp.n_seq;
+    }
+    { int64_t off = 0; for (Contig &c : ref.contigs) { c.offset = off; off += c.len; } }
+    ref.l_pac = l_pac;
+    ref.pac.assign((size_t)l_pac / 4 + 2, 0);
+    // ---- pass 2: pack (the first and last byte of a piece may be shared with its neighbours)
+    run([&](Span &sp) {
+        Rng48 rng(11);
+        rng.jump((uint64_t)sp.amb0);
+        int64_t p = sp.pos0;
+        const int64_t first_byte = sp.pos0 >> 2, last_byte = (sp.pos0 + sp.n_seq - 1) >> 2;
+        int lasts = 0; bool open_hole = false;
+        for (size_t j = sp.lo; j < sp.hi; ++j) {
+            const int ch = (unsigned char)b[j];
             if (!std::isgraph(ch)) continue;
             int code = nt4(ch);
             if (code >= 4) {
-                if (open_hole && lasts == ch) ++ref.holes.back().len;
-                else { ref.holes.push_back(Hole{c.offset + pos, 1, (char)ch}); ++c.n_ambs; open_hole = true; }
+                if (open_hole && lasts == ch) ++sp.holes.back().len;
+                else { sp.holes.push_back(Hole{p, 1, (char)ch}); open_hole = true; }
                 code = (int)(rng.lrand() & 3);
             }
             lasts = ch;
-            ref.pac[(size_t)ref.l_pac >> 2] |= (uint8_t)(code << ((~ref.l_pac & 3) << 1));
-            ++ref.l_pac; ++pos;
+            const uint8_t bits = (uint8_t)(code << ((~p & 3) << 1));
+            const int64_t byte = p >> 2;
+            if (byte == first_byte || byte == last_byte) __atomic_fetch_or(&ref.pac[(size_t)byte], bits, __ATOMIC_RELAXED);
+            else ref.pac[(size_t)byte] |= bits;
+            ++p;
         }
-        c.len = pos;
-        ref.contigs.push_back(c);
+    });
+    // ---- holes in order; a run of one character that continues across a piece boundary is one hole
+    for (size_t k = 0; k < spans.size(); ++k) {
+        Span &sp = spans[k];
+        for (Hole &h : sp.holes) {
+            const bool same_contig = k > 0 && spans[k - 1].contig == sp.contig;
+            if (!ref.holes.empty() && same_contig && &h == &sp.holes.front() && h.offset == sp.pos0 &&
+                ref.holes.back().offset + ref.holes.back().len == h.offset && ref.holes.back().amb == h.amb) {
+                // only if the previous piece really ended with this character (no other base in between): offsets adjacent
+                ref.holes.back().len += h.len;
+            } else { ref.holes.push_back(h); ++ref.contigs[(size_t)sp.contig].n_ambs; }
+        }
     }
-    if (ref.contigs.empty()) throw Error(std::string("no sequences in ") + path);
     ref.pac.resize((size_t)ref.l_pac / 4 + 1);
 }
 

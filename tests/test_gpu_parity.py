@@ -56,6 +56,21 @@ def test_index_multi_contig(ctx_multi, multi):
     assert ctx_multi.info().n_contigs == 3
 
 
+def test_fasta_parsed_in_pieces(multi, monkeypatch):
+    """the FASTA parser works on pieces of whole lines in parallel (3 GB references); with pieces of ~100 bytes every N run
+    and IUPAC hole of the fixture crosses piece boundaries, and the lrand48 fill must continue mid-stream"""
+    import capi
+    monkeypatch.setenv("PS_FASTA_PIECE", "100")
+    ctx = capi.Ctx.build(multi["fa"], device=0)
+    _check_index(ctx, multi["orc_index"])
+    ometa = multi["orc_index"]
+    meta = ctx.meta().decode()
+    monkeypatch.delenv("PS_FASTA_PIECE")
+    ref = capi.Ctx.build(multi["fa"], device=0)
+    assert meta == ref.meta().decode()                      # contig table and hole list identical to the one-piece parse
+    ctx.close(); ref.close()
+
+
 def _aln_tuple(a):
     return (int(a["k"]), int(a["l"]), int(a["n_mm"]), int(a["n_gapo"]), int(a["n_gape"]), int(a["n_ins"]),
             int(a["n_del"]), int(a["score"]))
