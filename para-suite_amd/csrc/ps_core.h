@@ -391,59 +391,27 @@ PS_HD void load_entry(const Entry *src, Entry &e)
 #endif
 }
 
-// push a child entry on its score bucket (LIFO linked list through the entries' next field).  `want` is the
-// caller's condition for this child: the narrow path is written with selects and ONE predicated region,
-// because every taken branch costs a divergent wave far more than a few masked instructions.
-template <bool WIDE>
-PS_HD void bt_push(const BtHot &a, BtLane &L, BtMem &m, bool want, int i, bwtint k, bwtint l, int n_mm, int n_gapo, int n_gape,
-                   int n_ins, int n_del, int state, bool is_diff, int score, int units)
+// wide stack (last tier): push a child entry on its score bucket (LIFO linked list through the entries' next field)
+PS_HD void bt_push_wide(const BtHot &a, BtLane &L, BtMem &m, bool want, int i, bwtint k, bwtint l, int n_mm, int n_gapo, int n_gape,
+                        int n_ins, int n_del, int state, bool is_diff, int score, int units)
 {
-    if (WIDE) {
-        if (!want || units > L.max_units) return;        // unaffordable children are not pushed (no-op with stock costs)
-        if (score >= a.n_buckets()) { L.status = RS_BAD_SCORE; return; }
-        Entry *pool = reinterpret_cast<Entry *>(m.pool);
-        uint32_t idx;
-        if (L.free_head != PS_NIL) { idx = L.free_head; L.free_head = pool[idx].next; }
-        else if (L.bump < a.pool_cap) idx = L.bump++;
-        else { L.status = RS_OVERFLOW_POOL; return; }
-        Entry e;
-        e.k = k; e.l = l; e.score = (uint16_t)score; e.units = (uint16_t)units;
-        e.i = (uint8_t)i; e.last_diff_pos = (uint8_t)(is_diff ? i : 0);
-        e.n_mm = (uint8_t)n_mm; e.n_gapo = (uint8_t)n_gapo; e.n_gape = (uint8_t)n_gape;
-        e.n_ins = (uint8_t)n_ins; e.n_del = (uint8_t)n_del; e.state = (uint8_t)state;
-        e.next = bm_test(L, score) ? m.heads[score] : PS_NIL;
-        store_entry(&pool[idx], e);
-        m.heads[score] = idx;
-        bm_set(L, score);
-        ++L.n_stack; ++L.st.pushes;
-    } else {
-        const bool afford = want && units <= L.max_units;              // unaffordable children are not pushed
-        const bool in_range = score < a.n_buckets();                   // always true (make_model sizes the buckets); guards the heads
-        const bool reuse = L.free_head != PS_NIL;                       // the slot of the entry popped last is reused first
-        const bool have_slot = reuse || L.bump < a.pool_cap;
-        const bool go = afford && in_range && have_slot;
-        L.status = (afford && !in_range) ? RS_BAD_SCORE : ((afford && in_range && !have_slot) ? RS_OVERFLOW_POOL : L.status);
-        const uint32_t idx = reuse ? L.free_head : L.bump;
-        const unsigned long long bit = 1ull << (score & 63);
-        const bool hi = (score & 64) != 0;
-        if (go) {
-            const bool nonempty = ((hi ? L.bm1 : L.bm0) & bit) != 0;
-            const uint32_t next = nonempty ? (uint32_t)m.heads16[score] : PS_NIL16;
-            Entry16 e;
-            e.k = (uint32_t)k; e.l = (uint32_t)l;
-            e.a = (uint32_t)i | ((uint32_t)(is_diff ? i : 0) << 8) | ((uint32_t)n_mm << 16) |
-                  (((uint32_t)state | ((uint32_t)n_gapo << 2) | ((uint32_t)n_gape << 5)) << 24);
-            e.b = (uint32_t)n_ins | ((uint32_t)n_del << 4) | ((uint32_t)score << 8) | (next << 16) | e16_hi(k, l);
-            store16(reinterpret_cast<Entry16 *>(m.pool) + idx, e);
-            m.heads16[score] = (uint16_t)idx;
-        }
-        L.bm0 |= (go && !hi) ? bit : 0ull;
-        L.bm1 |= (go && hi) ? bit : 0ull;
-        L.free_head = go ? PS_NIL : L.free_head;
-        L.bump += (go && !reuse) ? 1u : 0u;
-        L.n_stack += go ? 1 : 0;
-        L.st.pushes += go ? 1u : 0u;
-    }
+    if (!want || units > L.max_units) return;        // unaffordable children are not pushed (no-op with stock costs)
+    if (score >= a.n_buckets()) { L.status = RS_BAD_SCORE; return; }
+    Entry *pool = reinterpret_cast<Entry *>(m.pool);
+    uint32_t idx;
+    if (L.free_head != PS_NIL) { idx = L.free_head; L.free_head = pool[idx].next; }
+    else if (L.bump < a.pool_cap) idx = L.bump++;
+    else { L.status = RS_OVERFLOW_POOL; return; }
+    Entry e;
+    e.k = k; e.l = l; e.score = (uint16_t)score; e.units = (uint16_t)units;
+    e.i = (uint8_t)i; e.last_diff_pos = (uint8_t)(is_diff ? i : 0);
+    e.n_mm = (uint8_t)n_mm; e.n_gapo = (uint8_t)n_gapo; e.n_gape = (uint8_t)n_gape;
+    e.n_ins = (uint8_t)n_ins; e.n_del = (uint8_t)n_del; e.state = (uint8_t)state;
+    e.next = bm_test(L, score) ? m.heads[score] : PS_NIL;
+    store_entry(&pool[idx], e);
+    m.heads[score] = idx;
+    bm_set(L, score);
+    ++L.n_stack; ++L.st.pushes;
 }
 
 // ---- lean pushes of the narrow stack (the hot path).  The caller has checked once per expansion that nine
@@ -780,19 +748,19 @@ PS_HD void bt_iter(const BtArgs &a, const BtHot &h, BtLane &L, BtMem &m, int fet
         if (gap_ok) {
             if (e_st == ST_M) {
                 if (e_go < h.max_gapo()) {
-                    bt_push<WIDE>(h, L, m, true, i, ek, el, e_mm, e_go + 1, e_ge, e_ni + 1, e_nd, ST_I, true, e_sc + h.s_gapo_ins(), e_un + h.u_gapo_ins());
+                    bt_push_wide(h, L, m, true, i, ek, el, e_mm, e_go + 1, e_ge, e_ni + 1, e_nd, ST_I, true, e_sc + h.s_gapo_ins(), e_un + h.u_gapo_ins());
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        bt_push<WIDE>(h, L, m, ck[j] < cl[j], i + 1, h.L2(j) + ck[j] + 1, h.L2(j) + cl[j], e_mm, e_go + 1, e_ge, e_ni, e_nd + 1, ST_D, true, e_sc + h.s_gapo_del(), e_un + h.u_gapo_del());
+                        bt_push_wide(h, L, m, ck[j] < cl[j], i + 1, h.L2(j) + ck[j] + 1, h.L2(j) + cl[j], e_mm, e_go + 1, e_ge, e_ni, e_nd + 1, ST_D, true, e_sc + h.s_gapo_del(), e_un + h.u_gapo_del());
                 }
             } else if (e_st == ST_I) {
                 if (e_ge < h.max_gape())
-                    bt_push<WIDE>(h, L, m, true, i, ek, el, e_mm, e_go, e_ge + 1, e_ni + 1, e_nd, ST_I, true, e_sc + h.s_gape(), e_un + h.u_gape());
+                    bt_push_wide(h, L, m, true, i, ek, el, e_mm, e_go, e_ge + 1, e_ni + 1, e_nd, ST_I, true, e_sc + h.s_gape(), e_un + h.u_gape());
             } else {
                 if (e_ge < h.max_gape() && ((e_ge + e_go) * h.u_tight() < L.max_units || occ < (bwtint)h.max_del_occ())) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        bt_push<WIDE>(h, L, m, ck[j] < cl[j], i + 1, h.L2(j) + ck[j] + 1, h.L2(j) + cl[j], e_mm, e_go, e_ge + 1, e_ni, e_nd + 1, ST_D, true, e_sc + h.s_gape(), e_un + h.u_gape());
+                        bt_push_wide(h, L, m, ck[j] < cl[j], i + 1, h.L2(j) + ck[j] + 1, h.L2(j) + cl[j], e_mm, e_go, e_ge + 1, e_ni, e_nd + 1, ST_D, true, e_sc + h.s_gape(), e_un + h.u_gape());
                 }
             }
         }
@@ -805,7 +773,7 @@ PS_HD void bt_iter(const BtArgs &a, const BtHot &h, BtLane &L, BtMem &m, int fet
                 const uint32_t okc = sel4(ck, c), olc = sel4(cl, c);
                 const bwtint base = h.L2_dyn(c), k2 = base + okc + 1, l2 = base + olc;
                 const bool ok = okc < olc;
-                bt_push<WIDE>(h, L, m, ok && is_mm, i, k2, l2, e_mm + 1, e_go, e_ge, e_ni, e_nd, ST_M, true, e_sc + cost_of(h.s_pk, s, c), e_un + cost_of(h.u_pk, s, c));
+                bt_push_wide(h, L, m, ok && is_mm, i, k2, l2, e_mm + 1, e_go, e_ge, e_ni, e_nd, ST_M, true, e_sc + cost_of(h.s_pk, s, c), e_un + cost_of(h.u_pk, s, c));
                 if (ok && !is_mm) { // the match child has the parent's score and is pushed last: it is the next pop
                     L.k = k2; L.l = l2; L.i = i; L.state = ST_M; L.ldp = 0; L.have_cur = true;
                 }

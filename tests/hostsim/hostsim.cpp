@@ -186,16 +186,12 @@ int hs_unit_rows33(void)
         BtHot a; bt_hot_make(a0, a);
         bt_pop<false>(a, L, m);
         if (L.k != k || L.l != l || L.i != 17 || L.n_mm != 3 || L.state != ST_D || L.n_gapo != 2 || L.n_gape != 5 || L.n_ins != 7 || L.n_del != 6 || L.score != 9) return 1;
-        // general narrow push and the wide entry
+        // the wide entry
         const BtHot &aw = a;
-        memset(&L, 0, sizeof L); L.free_head = PS_NIL; L.cap = 64; L.max_units = 100;
-        bt_push<false>(aw, L, m, true, 21, k, l, 4, 1, 2, 3, 0, ST_I, true, 11, 11);
-        bt_pop<false>(aw, L, m);
-        if (L.k != k || L.l != l || L.i != 21 || L.n_ins != 3 || L.n_del != 0 || L.score != 11) return 2;
         std::vector<uint8_t> wpool(64 * sizeof(Entry), 0); std::vector<uint32_t> heads(PS_MAX_BUCKETS, 0);
         m.pool = wpool.data(); m.heads = heads.data();
         memset(&L, 0, sizeof L); L.free_head = PS_NIL; L.max_units = 100;
-        bt_push<true>(aw, L, m, true, 21, k, l, 4, 1, 2, 3, 0, ST_I, true, 11, 11);
+        bt_push_wide(aw, L, m, true, 21, k, l, 4, 1, 2, 3, 0, ST_I, true, 11, 11);
         bt_pop<true>(aw, L, m);
         if (L.k != k || L.l != l || L.i != 21) return 3;
     }
