@@ -230,6 +230,7 @@ struct BtLane {
     unsigned long long bm0, bm1;  // non-empty score buckets (two scalars: a dynamically indexed array would live in scratch)
     uint32_t bump, free_head, iters0;
     uint32_t rn0, rn1;             // N mask of a read of up to 64 bases (read orientation)
+    int len;                       // this read's length (reads of one cost class share a launch; the layout is for the longest)
     uint32_t n_phantom;            // narrow stack: children not stored because the D(i) bound already rules them out (see bt_iter)
     uint32_t cap;                  // capacity of the stack this lane currently uses (private slice, or a large slot after M_GROW)
     LaneStats st;
@@ -326,11 +327,11 @@ PS_HD void bt_mem_bind(BtMem &m, uint8_t *mine, int len, int seed_len)
     m.heads16 = reinterpret_cast<uint16_t *>(mine + lm_heads_off(len, seed_len));
 }
 // base j of the reverse-complemented read (what the search consumes): 0..3, 4 = N
-PS_HD int seq_at(const BtMem &m, const BtLane &L, int j, int len)
+PS_HD int seq_at(const BtMem &m, const BtLane &L, int j, int len, int max_len)
 {
     const int p = len - 1 - j;
     const uint32_t b = (m.rb[p >> 4] >> (2 * (p & 15))) & 3u;
-    const uint32_t nw = lm_nmask_in_regs(len) ? (p < 32 ? L.rn0 : L.rn1) : m.rn[p >> 5];
+    const uint32_t nw = lm_nmask_in_regs(max_len) ? (p < 32 ? L.rn0 : L.rn1) : m.rn[p >> 5];
     return ((nw >> (p & 31)) & 1u) ? 4 : 3 - (int)b;
 }
 
@@ -567,8 +568,9 @@ PS_COLD void bt_hit(const BtArgs &a, BtLane &L, BtMem &m)
 PS_COLD bool bt_fetch(const BtArgs &a, BtLane &L, BtMem &m, int fetch_r)
 {
     const Model &md = a.md;
-    const int len = a.len;
         const int r = fetch_r;
+        const int len = a.lens ? a.lens[r] : a.len;
+        L.len = len;
         L.r = r; L.status = RS_OK; L.n_aln = 0; L.iters0 = L.st.iters;
         // load the compact widths and the packed read into local memory (whole words, coalesced across lanes)
         {
@@ -576,13 +578,15 @@ PS_COLD bool bt_fetch(const BtArgs &a, BtLane &L, BtMem &m, int fetch_r)
             uint32_t *cw32 = reinterpret_cast<uint32_t *>(m.cw), *csw32 = reinterpret_cast<uint32_t *>(m.csw);
             for (int p = 0; p < ncw; ++p) cw32[p] = a.cwb[(size_t)p * a.n_reads + r];
             for (int p = 0; p < ncsw; ++p) csw32[p] = a.cswb[(size_t)p * a.n_reads + r];
-            for (int p = 0; p < a.n_bw; ++p) m.rb[p] = a.bases[(size_t)p * a.n_reads + r];
+            const int nbw = (len + 15) >> 4;
+            for (int p = 0; p < nbw; ++p) m.rb[p] = a.bases[(size_t)p * a.n_reads + r];
         }
         int nNu = 0;
         L.rn0 = L.rn1 = 0;
-        for (int p = 0; p < a.n_mw; ++p) {
+        const int nmw = (len + 31) >> 5;
+        for (int p = 0; p < nmw; ++p) {
             uint32_t w = a.nmask[(size_t)p * a.n_reads + r];
-            if (lm_nmask_in_regs(len)) { if (p == 0) L.rn0 = w; else L.rn1 = w; }
+            if (lm_nmask_in_regs(a.len)) { if (p == 0) L.rn0 = w; else L.rn1 = w; }
             else m.rn[p] = w;
             nNu += (int)ps_popc(w) * (int)(md.u_mm_pk[4] & 0xffu);
         }
@@ -601,7 +605,6 @@ PS_COLD bool bt_fetch(const BtArgs &a, BtLane &L, BtMem &m, int fetch_r)
 template <bool WIDE>
 PS_HD void bt_iter(const BtArgs &a, const BtHot &h, BtLane &L, BtMem &m, int fetch_r, bool serve_hit)
 {
-    const int len = h.len();
     if (L.mode == M_EXIT || L.mode == M_GROW) return;   // retired lane / lane waiting for a larger stack: nothing to do here
     ++L.st.iters;
     if (L.mode == M_HIT) {
@@ -642,12 +645,13 @@ PS_HD void bt_iter(const BtArgs &a, const BtHot &h, BtLane &L, BtMem &m, int fet
         }
     }
     if (L.mode != M_EXACT && L.mode != M_EXPAND) return;
+    const int len = L.len, max_len = h.len();      // the read's own length; the launch's longest (layout of the local memory)
     // ---- the memory step, shared by both search modes: Occ(k-1,.) and Occ(l,.) -> the four child intervals ----
     uint32_t ck[4], cl[4];
     occ_pair4(h.blocks, h.primary, L.k, L.l, ck, cl, L.st);
     // child interval of text symbol c: rows [L2[c]+ck[c]+1, L2[c]+cl[c]], non-empty iff ck[c] < cl[c]
     if (L.mode == M_EXACT) {          // no difference left: extend exactly, one base per iteration
-        const int c = seq_at(m, L, L.i - 1, len);
+        const int c = seq_at(m, L, L.i - 1, len, max_len);
         ++L.st.exact;
         if (c > 3) { L.mode = M_POP; return; }
         const uint32_t ok = sel4(ck, c), ol = sel4(cl, c);
@@ -687,7 +691,7 @@ PS_HD void bt_iter(const BtArgs &a, const BtHot &h, BtLane &L, BtMem &m, int fet
         const int e_sc = L.score, e_un = L.units, e_st = L.state;
         const bwtint ek = L.k, el = L.l;
         const int tmp = e_go + e_ge;
-        const int s = seq_at(m, L, i, len);
+        const int s = seq_at(m, L, i, len, max_len);
         const bool gap_ok = allow_diff && i >= h.indel_end_skip() + tmp && len - i >= h.indel_end_skip() + tmp;
         if (!WIDE) {
             // ---- narrow stack: lean pushes ----

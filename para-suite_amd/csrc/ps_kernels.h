@@ -10,6 +10,7 @@ static const int PS_MAX_CIGAR = 16;
 struct WidthArgs {
     IndexView ix;
     int n_reads, len, seed_len, use_seed;
+    const int32_t *lens;     // per-read lengths (nullptr: all len)
     const uint32_t *bases; const uint32_t *nmask;
     uint32_t *w; uint32_t *cwb; uint32_t *cswb;   // compact width bytes, 4 positions per word, [word][n_reads]
     KStats *stats;
@@ -18,7 +19,8 @@ struct WidthArgs {
 struct RefineItem { int32_t read; bwtint rb; int32_t ref_shift; int32_t strand; };
 struct RefineArgs {
     IndexView ix;
-    int n_items, len, n_reads;
+    int n_items, len, n_reads;             // len: the longest read (sizes the H/E rows)
+    const int32_t *lens;                   // per-read lengths (nullptr: all len)
     const uint32_t *bases; const uint32_t *nmask;
     const RefineItem *items;
     uint32_t *cigar; int32_t *n_cigar;     // [n_items][PS_MAX_CIGAR]

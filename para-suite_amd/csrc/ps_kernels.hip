@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(256) k_width(WidthArgs a)
     for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < a.n_reads; r += stride) {
         WChain A, B;
         wchain_init(a.ix, A); wchain_init(a.ix, B);
-        const int len = a.len, seed_len = a.seed_len;
+        const int len = a.lens ? a.lens[r] : a.len, seed_len = a.seed_len;
         uint32_t bw = 0, mw = 0, sbw = 0, smw = 0;  // current base / N-mask words of the two chains
         uint32_t cww = 0, csww = 0;                  // compact width bytes being assembled, 4 positions per word
         for (int i = 0; i < len; ++i) {
@@ -231,10 +231,11 @@ __global__ void __launch_bounds__(64) k_refine(RefineArgs a)
     uint8_t *z = a.zbuf + (size_t)blockIdx.x * a.z_per_block + threadIdx.x;
     for (int it = blockIdx.x * 64 + threadIdx.x; it < a.n_items; it += gridDim.x * 64) {
         RefineItem q = a.items[it];
-        int tlen = a.len + q.ref_shift;
-        int d = tlen - a.len; if (d < 0) d = -d;
+        const int qlen = a.lens ? a.lens[q.read] : a.len;
+        int tlen = qlen + q.ref_shift;
+        int d = tlen - qlen; if (d < 0) d = -d;
         int w = (int)(d * 1.5); if (w < 50) w = 50;
-        const int r = q.read, len = a.len, n_reads = a.n_reads;
+        const int r = q.read, len = qlen, n_reads = a.n_reads;
         const uint32_t *bases = a.bases, *nmask = a.nmask;
         const int strand = q.strand;
         uint32_t cig[PS_MAX_CIGAR];

@@ -88,8 +88,13 @@ struct Ctx {
     ~Ctx();
 };
 
+// Reads of one *cost class* -- lengths that get the same difference budget, seed rule and local-memory layout --
+// share a bin and a launch; len is the longest of them, lens the length of every read (adapter-trimmed input has
+// dozens of lengths: one launch per length would leave the device mostly idle).
 struct Bin {
     int len = 0; Model md;
+    bool ragged = false;                      // more than one length present
+    std::vector<int32_t> lens; DevBuf<int32_t> d_lens;     // bin-local; d_lens allocated only when ragged
     std::vector<int32_t> ids;                 // global read index of every local read
     DevBuf<uint32_t> bases, nmask, w; DevBuf<uint8_t> cwb, cswb, status; DevBuf<AlnRec> alns; DevBuf<int32_t> n_aln;
     std::vector<uint32_t> h_bases, h_nmask;   // host copy (tier re-runs gather from it)

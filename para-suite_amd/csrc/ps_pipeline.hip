@@ -225,14 +225,25 @@ std::unique_ptr<Batch> batch_create(Ctx *ctx, ReadSet &&rs_in)
     b->wk = ctx->take_work();
     Work *wk = b->wk;
     const ReadSet &rs = b->rs;
-    std::map<int, int> bin_of_len;
+    // cost class of a length: everything of the search model that depends on the length except the length itself
+    std::map<int, int> class_of_len;                     // length -> bin
+    std::map<std::vector<int>, int> bin_of_class;
     b->read_bin.resize((size_t)rs.n); b->read_local.resize((size_t)rs.n);
     for (int64_t g = 0; g < rs.n; ++g) {
         int len = rs.len[g];
         if (len < 1) throw Error("empty read in input");
-        auto it = bin_of_len.find(len);
-        if (it == bin_of_len.end()) { it = bin_of_len.emplace(len, (int)b->bins.size()).first; b->bins.emplace_back(); b->bins.back().len = len; }
+        auto it = class_of_len.find(len);
+        if (it == class_of_len.end()) {
+            Model md; std::string err;
+            if (!make_model(ctx->opt, len, md, err)) throw Error(err);
+            const std::vector<int> key = {md.max_units, md.max_gapo, md.use_seed, md.seed_len, md.n_buckets, lm_nmask_in_regs(len) ? 1 : 0, (len + 15) / 16};
+            auto bc = bin_of_class.find(key);
+            if (bc == bin_of_class.end()) { bc = bin_of_class.emplace(key, (int)b->bins.size()).first; b->bins.emplace_back(); }
+            it = class_of_len.emplace(len, bc->second).first;
+        }
         Bin &bin = b->bins[it->second];
+        if (bin.len && bin.len != len) bin.ragged = true;
+        if (len > bin.len) bin.len = len;
         b->read_bin[g] = it->second; b->read_local[g] = (int32_t)bin.ids.size();
         bin.ids.push_back((int32_t)g);
     }
@@ -244,10 +255,10 @@ std::unique_ptr<Batch> batch_create(Ctx *ctx, ReadSet &&rs_in)
         // Results return to input order through ids[]; the order inside a bin is free.
         {
             const size_t n = bin.ids.size();
-            const int kb = bin.len < 16 ? bin.len : 16;
             std::vector<uint32_t> key(n), key2(n); std::vector<int32_t> id2(n);
             for (size_t r = 0; r < n; ++r) {
                 const uint8_t *sq = rs.seq.data() + rs.off[bin.ids[r]];
+                const int kb = rs.len[bin.ids[r]] < 16 ? rs.len[bin.ids[r]] : 16;
                 uint32_t k = 0;
                 for (int j = 0; j < kb; ++j) k = (k << 2) | (uint32_t)(sq[j] & 3);
                 key[r] = k << (2 * (16 - kb));
@@ -269,7 +280,8 @@ std::unique_ptr<Batch> batch_create(Ctx *ctx, ReadSet &&rs_in)
             auto pack = [&](int t) {                                  // distinct reads write distinct words: no sharing
                 for (size_t r = n * t / nt; r < n * (t + 1) / nt; ++r) {
                     const uint8_t *s = rs.seq.data() + rs.off[bin.ids[r]];
-                    for (int j = 0; j < bin.len; ++j) {
+                    const int rl = rs.len[bin.ids[r]];
+                    for (int j = 0; j < rl; ++j) {
                         if (s[j] > 3) bin.h_nmask[(size_t)(j >> 5) * n + r] |= 1u << (j & 31);
                         else bin.h_bases[(size_t)(j >> 4) * n + r] |= (uint32_t)s[j] << (2 * (j & 15));
                     }
@@ -280,6 +292,9 @@ std::unique_ptr<Batch> batch_create(Ctx *ctx, ReadSet &&rs_in)
             pack(0);
             for (auto &x : th) x.join();
         }
+        bin.lens.resize(n);
+        for (size_t r = 0; r < n; ++r) bin.lens[r] = rs.len[bin.ids[r]];
+        if (bin.ragged) { bin.d_lens.alloc(n); bin.d_lens.upload(bin.lens.data(), n, wk->stream); }
         bin.d_ids.alloc(n); bin.d_ids.upload(bin.ids.data(), n, wk->stream);
         bin.bases.alloc(bin.h_bases.size()); bin.nmask.alloc(bin.h_nmask.size());
         bin.bases.upload(bin.h_bases.data(), bin.h_bases.size(), wk->stream);
@@ -331,7 +346,7 @@ template <class F> static void par_for(size_t n, int threads, F f)
 static int par_threads(size_t n, int threads) { size_t nt = (size_t)std::max(1, threads); if (nt > n / 8192 + 1) nt = n / 8192 + 1; return (int)std::max<size_t>(1, nt); }
 
 // width + backtracking kernels over n reads of one length that are already packed on the device
-static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases, const uint32_t *d_nmask,
+static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases, const uint32_t *d_nmask, const int32_t *d_lens,
                        uint32_t pool_cap, int aln_cap, AlnRec *alns, int32_t *n_aln, uint8_t *status)
 {
     Ctx *ctx = b.ctx; Work *wk = b.wk; hipStream_t s = wk->stream;
@@ -340,7 +355,7 @@ static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases
     uint32_t *cwb = wk->ws_get<uint32_t>("cwb", (size_t)lm_ncw(len) * n);
     uint32_t *cswb = wk->ws_get<uint32_t>("cswb", (size_t)(lm_ncsw(seed_len) + 1) * n);
     WidthArgs wa;
-    wa.ix = ctx->ix.view; wa.n_reads = n; wa.len = len; wa.seed_len = seed_len; wa.use_seed = md.use_seed;
+    wa.ix = ctx->ix.view; wa.n_reads = n; wa.len = len; wa.lens = d_lens; wa.seed_len = seed_len; wa.use_seed = md.use_seed;
     wa.bases = d_bases; wa.nmask = d_nmask; wa.w = w; wa.cwb = cwb; wa.cswb = cswb; wa.stats = b.d_stats.p + 0;
     { EvTimer t(s); launch_width(wa, s); PS_HIP(hipGetLastError()); b.tm.ms_width += t.stop(); ++b.tm.n_width_launches; }
     int dev_cus = 256;
@@ -363,7 +378,7 @@ static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases
     uint32_t *queue = wk->ws_get<uint32_t>("queue", 16);
     PS_HIP(hipMemsetAsync(queue, 0, 64, s));
     BtArgs a; std::memset(&a, 0, sizeof a);
-    a.ix = ctx->ix.view; a.md = md; a.n_reads = n; a.len = len; a.n_lanes = n_lanes;
+    a.ix = ctx->ix.view; a.md = md; a.n_reads = n; a.len = len; a.lens = d_lens; a.n_lanes = n_lanes;
     a.bases = d_bases; a.nmask = d_nmask; a.n_bw = (len + 15) / 16; a.n_mw = (len + 31) / 32;
     a.w = w; a.cwb = cwb; a.cswb = cswb;
     a.alns = alns; a.aln_cap = aln_cap; a.n_aln = n_aln; a.status = status;
@@ -510,7 +525,7 @@ __global__ void k_select(SelectArgs a)
 }
 
 struct PostArgs {
-    const int32_t *ids; int n, len; long long l_pac;
+    const int32_t *ids; int n, len; const int32_t *lens; long long l_pac;
     const uint8_t *cls; const SelRec *sel; const bwtint *pos; FinRec *fin;
     int budget, profile, unit; const uint8_t *logn;     // MAPQ rule inputs; logn[n] = (int)(4.343 ln n + .5)
     RefineItem *items; int32_t *item_g; unsigned int *n_items;
@@ -524,7 +539,7 @@ __global__ void k_post(PostArgs a)
         const SelRec s = a.sel[g];
         if (a.cls[g] == 1 && s.type != 0) {
             long long pos_f = (long long)a.pos[g];
-            const int ref_len = a.len + s.ref_shift;
+            const int ref_len = (a.lens ? a.lens[r] : a.len) + s.ref_shift;
             int strand = 0; long long p = -1;
             if (!(pos_f < a.l_pac && a.l_pac < pos_f + ref_len)) {
                 const bool is_rev = pos_f >= a.l_pac;
@@ -567,7 +582,7 @@ void batch_search(Batch &b)
         bin.host_alns_valid = false;
         if (bin.d_alns.n < (size_t)n * ctx->aln_cap[0]) { bin.d_alns.alloc((size_t)n * ctx->aln_cap[0]); bin.d_n_aln.alloc(n); bin.d_status.alloc(n); }
         bin.aln_cap = ctx->aln_cap[0];
-        run_search(b, bin.md, n, bin.bases.p, bin.nmask.p, ctx->pool_cap[0], bin.aln_cap, bin.d_alns.p, bin.d_n_aln.p, bin.d_status.p);
+        run_search(b, bin.md, n, bin.bases.p, bin.nmask.p, bin.ragged ? bin.d_lens.p : nullptr, ctx->pool_cap[0], bin.aln_cap, bin.d_alns.p, bin.d_n_aln.p, bin.d_status.p);
         uint8_t *h_status = wk->pin_get<uint8_t>("status", n);
         PS_HIP(hipMemcpyAsync(h_status, bin.d_status.p, (size_t)n, hipMemcpyDeviceToHost, s));
         hipLaunchKernelGGL(k_classify, dim3(std::min((n + 255) / 256, 4096)), dim3(256), 0, s, bin.d_alns.p, bin.aln_cap, bin.d_n_aln.p, bin.d_status.p,
@@ -590,9 +605,11 @@ void batch_search(Batch &b)
             }
             DevBuf<uint32_t> db, dm; db.alloc(hb.size()); dm.alloc(hm.size());
             db.upload(hb.data(), hb.size(), s); dm.upload(hm.data(), hm.size(), s);
+            std::vector<int32_t> hl(m); DevBuf<int32_t> dl;
+            if (bin.ragged) { for (int q = 0; q < m; ++q) hl[q] = bin.lens[todo[q]]; dl.alloc(m); dl.upload(hl.data(), m, s); }
             DevBuf<AlnRec> ta; DevBuf<int32_t> tn; DevBuf<uint8_t> ts;
             ta.alloc((size_t)m * ctx->aln_cap[tier]); tn.alloc(m); ts.alloc(m);
-            run_search(b, bin.md, m, db.p, dm.p, ctx->pool_cap[tier], ctx->aln_cap[tier], ta.p, tn.p, ts.p);
+            run_search(b, bin.md, m, db.p, dm.p, bin.ragged ? dl.p : nullptr, ctx->pool_cap[tier], ctx->aln_cap[tier], ta.p, tn.p, ts.p);
             std::vector<uint8_t> st(m); ts.download(st.data(), m, s);
             std::vector<int32_t> na; std::vector<uint32_t> off; std::vector<AlnRec> al;
             download_alns(wk, m, ctx->aln_cap[tier], ta.p, tn.p, na, off, al);
@@ -892,7 +909,7 @@ static void run_refine(Batch &b, Bin &bin, const RefineItem *d_items, int n_it, 
     int blocks = (n_it + 63) / 64; if (blocks > 2048) blocks = 2048;
     const int tmax = bin.len + 64;
     RefineArgs ra;
-    ra.ix = ctx->ix.view; ra.n_items = n_it; ra.len = bin.len; ra.n_reads = (int)bin.ids.size();
+    ra.ix = ctx->ix.view; ra.n_items = n_it; ra.len = bin.len; ra.lens = bin.ragged ? bin.d_lens.p : nullptr; ra.n_reads = (int)bin.ids.size();
     ra.bases = bin.bases.p; ra.nmask = bin.nmask.p; ra.items = d_items; ra.cigar = d_cig; ra.n_cigar = d_nc;
     ra.z_per_block = (size_t)64 * tmax * (bin.len < 2 * tmax + 1 ? bin.len : 2 * tmax + 1);
     ra.zbuf = wk->ws_get<uint8_t>("rf_z", ra.z_per_block * blocks);
@@ -927,7 +944,7 @@ void batch_locate(Batch &b)
         it.d_n = wk->ws_get<unsigned int>("post_n" + std::to_string(bi), 4);
         PS_HIP(hipMemsetAsync(it.d_n, 0, 16, s));
         PostArgs a;
-        a.ids = bin.d_ids.p; a.n = n; a.len = bin.len; a.l_pac = l_pac; a.cls = b.d_class.p; a.sel = b.d_sel.p; a.pos = b.d_pos.p; a.fin = b.d_fin.p;
+        a.ids = bin.d_ids.p; a.n = n; a.len = bin.len; a.lens = bin.ragged ? bin.d_lens.p : nullptr; a.l_pac = l_pac; a.cls = b.d_class.p; a.sel = b.d_sel.p; a.pos = b.d_pos.p; a.fin = b.d_fin.p;
         a.budget = budget_diffs(ctx->opt, bin.len); a.profile = ctx->opt.profile; a.unit = ctx->opt.unit; a.logn = d_logn;
         a.items = it.d_items; a.item_g = it.d_item_g; a.n_items = it.d_n;
         hipLaunchKernelGGL(k_post, dim3(std::min((n + 255) / 256, 4096)), dim3(256), 0, s, a);

@@ -88,7 +88,8 @@ struct KStats {            // per-launch counters (roofline accounting)
 struct BtArgs {
     IndexView ix;
     Model md;
-    int n_reads, len, n_lanes;
+    int n_reads, len, n_lanes;                        // len: the longest read of the launch (layout); lens: every read's own
+    const int32_t *lens;                              // nullptr: all reads have length len
     // reads: 2-bit bases [w][n_reads] (base j of a read: word j>>4, bits 2*(j&15)), N mask [j>>5][n_reads]
     const uint32_t *bases; const uint32_t *nmask; int n_bw, n_mw;
     // from the width kernel, [pos][n_reads]: interval sizes w (updated by hit shadowing), compact
