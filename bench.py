@@ -324,8 +324,8 @@ def main():
                          "avg_launch_ms": (ms_bt_step if dominant_bt else ms_w_step) / launches_per_step,
                          "launches_per_step": launches_per_step,
                          "width_kernel": {"achieved": alg_w / (ms_w_step * 1e-3) / 1e9, "frac": alg_w / (ms_w_step * 1e-3) / 1e9 / 8000.0}},
-            "kernels_ms_per_step": {k: acc[k] / K for k in ("ms_width", "ms_backtrack", "ms_compact", "ms_select", "ms_sa2pos",
-                                                            "ms_refine", "ms_host_post", "ms_classify", "ms_rows", "ms_sel_hard", "ms_sel_easy")},
+            "kernels_ms_per_step": {k: acc[k] / K for k in ("ms_width", "ms_backtrack", "ms_select", "ms_sa2pos",
+                                                            "ms_refine", "ms_host_post", "ms_classify", "ms_sel_hard", "ms_sel_easy")},
             "stage_wall_ms_per_step": {k: 1e3 * v / K for k, v in wall.items()},
             "kstats": {"backtrack": ks_bt, "width": ks_w, "sa2pos": ks_sa},
             "mapped_frac": float((hits["type"] != 0).mean()),
