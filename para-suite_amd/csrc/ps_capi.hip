@@ -365,7 +365,8 @@ int ps_map(int threads, const char *mm, const char *error_profile, const char *i
                 if (werr) break;
             }
             (void)header_only;
-        } catch (const std::exception &e) { rc = 1; msg = e.what(); parsed.abort(); }
+        } catch (const std::exception &e) { rc = 1; msg = e.what(); }
+        parsed.abort();                           // a parser still waiting to hand over a piece must not wait forever
         mapped.close();
         parser.join(); writer.join();
         if (!rc && perr) { try { std::rethrow_exception(perr); } catch (const std::exception &e) { rc = 1; msg = e.what(); } }

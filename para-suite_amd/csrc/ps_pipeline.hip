@@ -54,8 +54,9 @@ static inline uint8_t code_of(int ch)
 // one parser pass over buf[i0, i1): appends to rs (offsets relative to rs's own arrays)
 static void parse_reads_range(const char *buf, size_t i0, size_t i1, ReadSet &rs, bool &any_qual)
 {
-    static uint8_t lut[256]; static bool lut_ok = false;
-    if (!lut_ok) { for (int c = 0; c < 256; ++c) lut[c] = code_of(c); lut_ok = true; }
+    struct Lut { uint8_t v[256]; Lut() { for (int c = 0; c < 256; ++c) v[c] = code_of(c); } };
+    static const Lut lut_obj;                       // initialised once, safely, however many parser threads arrive
+    const uint8_t *lut = lut_obj.v;
     size_t i = i0;
     const size_t n = i1;
     while (i < n) {

@@ -266,3 +266,26 @@ def test_ps_map_streams_in_pieces(mid, workdir, monkeypatch):
     assert len(g) == len(o) == 40000
     bad = [i for i in range(len(g)) if g[i] != o[i]]
     assert not bad, (len(bad), g[bad[0]], o[bad[0]])
+
+
+def test_ps_map_reports_errors_without_hanging(mid, workdir):
+    """failures in the parser or the writer thread of ps_map come back as an error status (Mapping.executeCommand's
+    contract: non-zero, message) -- and the other stages are released, no thread waits forever"""
+    import capi
+    fa = mid["fa"]
+    if not os.path.exists(fa + ".bwt"):
+        capi.ps_index(fa)
+    fq = os.path.join(workdir, "stream.fq")                # written by the streaming test; recreate if run alone
+    if not os.path.exists(fq):
+        import simulate as S
+        S.write_fastq(fq, S.simulate_reads(mid["genome"], n_reads=40000, read_len=50, seed=77))
+    with pytest.raises(capi.PsError):
+        capi.ps_map(4, "0.04", None, None, fa, os.path.join(workdir, "no_such.fq"), os.path.join(workdir, "x.sam"))
+    os.environ["PS_CHUNK_MB"] = "1"
+    try:
+        with pytest.raises(capi.PsError):
+            capi.ps_map(4, "0.04", None, None, fa, fq, os.path.join(workdir, "no_such_dir", "x.sam"))
+    finally:
+        del os.environ["PS_CHUNK_MB"]
+    with pytest.raises(capi.PsError):
+        capi.ps_map(4, "0.04", os.path.join(workdir, "no_such.errorprofile"), None, fa, fq, os.path.join(workdir, "y.sam"))
