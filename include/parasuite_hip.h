@@ -102,6 +102,14 @@ int     ps_batch_kstats(ps_batch *, int which /*0 width 1 backtrack 2 sa2pos*/, 
 typedef struct { uint64_t n_in, n_out, bam_bytes; } ps_bam_stats;
 int     ps_sam_to_bam(const char *sam, const char *bam, int min_mapq, int sort_by_coordinate, int write_index, int threads,
                       ps_bam_stats *stats /* may be NULL */);
+/* the same steps one by one on BAM input, as the unmodified Java issues them (an argv-compatible `samtools` for exactly
+ * these four command shapes is built as para-suite_amd/bin/samtools):
+ *   samtools view -q <mapq> -b in.bam -o out.bam   (PARAsuiteMapping.java:121-133)
+ *   samtools sort [-n] in.bam -o out.bam            (Mapping.java:86-93, 118-126; -n: names ordered as samtools does)
+ *   samtools index in.bam                           (Mapping.java:100-105)  -> in.bam.bai, the BAM is not rewritten */
+int     ps_bam_view(const char *in_bam, const char *out_bam, int min_mapq, int threads, ps_bam_stats *stats);
+int     ps_bam_sort(const char *in_bam, const char *out_bam, int by_name, int threads, ps_bam_stats *stats);
+int     ps_bam_index(const char *bam, int threads);
 
 #ifdef __cplusplus
 }

@@ -40,7 +40,7 @@ HIT_DTYPE = np.dtype([("pos", "<i8"), ("sa", "<u8"), ("type", "<i4"), ("strand",
 
 EXPORTS = ["ps_version", "ps_last_error", "ps_index", "ps_map", "ps_ctx_open", "ps_ctx_build", "ps_ctx_close",
            "ps_ctx_set_stock", "ps_ctx_set_profile", "ps_ctx_set_profile_matrix", "ps_ctx_set_tiers", "ps_ctx_info",
-           "ps_ctx_blob", "ps_ctx_meta", "ps_ctx_from_blobs", "ps_ctx_fetch", "ps_ctx_export_blob", "ps_sam_to_bam", "ps_batch_from_fastq",
+           "ps_ctx_blob", "ps_ctx_meta", "ps_ctx_from_blobs", "ps_ctx_fetch", "ps_ctx_export_blob", "ps_sam_to_bam", "ps_bam_view", "ps_bam_sort", "ps_bam_index", "ps_batch_from_fastq",
            "ps_batch_from_codes", "ps_batch_free", "ps_batch_n", "ps_batch_search", "ps_batch_select_hard",
            "ps_batch_select_easy", "ps_batch_locate", "ps_batch_run", "ps_batch_write_sam", "ps_batch_n_aln",
            "ps_batch_alns", "ps_batch_hits", "ps_batch_timing", "ps_batch_kstats", "ps_ctx_read_iters"]
@@ -319,3 +319,24 @@ def ps_sam_to_bam(sam, bam, min_mapq=0, sort_by_coordinate=False, write_index=Fa
     _chk(L.ps_sam_to_bam(sam.encode(), bam.encode(), int(min_mapq), int(bool(sort_by_coordinate)), int(bool(write_index)),
                          int(threads), C.byref(st)))
     return dict(n_in=st.n_in, n_out=st.n_out, bam_bytes=st.bam_bytes)
+
+
+def _bam_call(fn, *args):
+    st = BamStats()
+    _chk(fn(*args, C.byref(st)))
+    return dict(n_in=st.n_in, n_out=st.n_out, bam_bytes=st.bam_bytes)
+
+
+def ps_bam_view(in_bam, out_bam, min_mapq=0, threads=8):
+    L = lib(); L.ps_bam_view.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(BamStats)]
+    return _bam_call(L.ps_bam_view, in_bam.encode(), out_bam.encode(), int(min_mapq), int(threads))
+
+
+def ps_bam_sort(in_bam, out_bam, by_name=False, threads=8):
+    L = lib(); L.ps_bam_sort.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(BamStats)]
+    return _bam_call(L.ps_bam_sort, in_bam.encode(), out_bam.encode(), int(bool(by_name)), int(threads))
+
+
+def ps_bam_index(bam, threads=8):
+    L = lib(); L.ps_bam_index.argtypes = [C.c_char_p, C.c_int]
+    _chk(L.ps_bam_index(bam.encode(), int(threads)))

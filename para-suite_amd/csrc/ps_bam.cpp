@@ -1,4 +1,4 @@
-// ps_bam.cpp -- SAM text -> BAM (BGZF), MAPQ filter, coordinate sort and .bai index in one pass over memory.
+// ps_bam.cpp -- SAM text -> BAM (BGZF), MAPQ filter, coordinate / name sort and .bai index, on SAM or BAM input.
 //
 // §8f rank 3: what /root/reference/src/src/mapping/PARAsuiteMapping.java:102-133 (`samtools view -bS`,
 // `samtools view -q <mapq> -b`) and Mapping.java:85-108 (`samtools sort`, `samtools index`) spawn four
@@ -7,6 +7,7 @@
 // integer tags take the smallest type as htslib's SAM parser does.  Host code only (zlib), no device work.
 #include <zlib.h>
 #include <algorithm>
+#include <cctype>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -186,12 +187,28 @@ template <class F> static void par(int n, int threads, F f)
 
 }  // namespace
 
-void sam_to_bam(const char *sam_path, const char *bam_path, int min_mapq, bool sort_by_coordinate, bool write_index, int threads, BamStats *stats)
+namespace {
+
+struct Data {                       // a BAM in memory: header, reference table, encoded records in parts
+    std::string text; std::vector<std::pair<std::string, uint32_t>> refs;
+    std::vector<std::string> enc; std::vector<Rec> recs; uint64_t n_in = 0;
+};
+
+static void header_sorted(std::string &text, const char *so)
 {
-    if (threads < 1) threads = 1;
-    if (threads > 64) threads = 64;
-    if (write_index && !sort_by_coordinate) throw Err("a .bai index needs coordinate-sorted output");
-    // ---- read the SAM text
+    if (text.compare(0, 3, "@HD") == 0) {
+        const size_t e = text.find('\n');
+        std::string hd = text.substr(0, e);
+        const size_t at = hd.find("\tSO:");
+        if (at != std::string::npos) { size_t q = hd.find('\t', at + 1); hd.erase(at, (q == std::string::npos ? hd.size() : q) - at); }
+        hd += std::string("\tSO:") + so;
+        text = hd + text.substr(e);
+    } else text = std::string("@HD\tVN:1.6\tSO:") + so + "\n" + text;
+}
+
+// ---- SAM text -> Data
+static void load_sam(const char *sam_path, int min_mapq, int threads, Data &d)
+{
     FILE *f = std::fopen(sam_path, "rb");
     if (!f) throw Err(std::string("cannot open ") + sam_path);
     std::fseek(f, 0, SEEK_END); const long sz = std::ftell(f); std::fseek(f, 0, SEEK_SET);
@@ -199,8 +216,7 @@ void sam_to_bam(const char *sam_path, const char *bam_path, int min_mapq, bool s
     if (sz && std::fread(buf.data(), 1, (size_t)sz, f) != (size_t)sz) { std::fclose(f); throw Err(std::string("short read on ") + sam_path); }
     std::fclose(f);
     const size_t n = (size_t)sz; const char *b = buf.data();
-    // ---- header
-    std::string text; std::vector<std::pair<std::string, uint32_t>> refs; std::map<std::string, int> ref_id;
+    std::map<std::string, int> ref_id;
     size_t body = 0;
     while (body < n && b[body] == '@') {
         const char *e = (const char *)std::memchr(b + body, '\n', n - body);
@@ -216,22 +232,12 @@ void sam_to_bam(const char *sam_path, const char *bam_path, int min_mapq, bool s
                 p = q + 1;
             }
             if (name.empty() || ln <= 0) throw Err("bad @SQ line: " + line);
-            ref_id[name] = (int)refs.size(); refs.emplace_back(name, (uint32_t)ln);
+            ref_id[name] = (int)d.refs.size(); d.refs.emplace_back(name, (uint32_t)ln);
         }
-        text += line; text.push_back('\n');
+        d.text += line; d.text.push_back('\n');
         body = j < n ? j + 1 : n;
     }
-    if (sort_by_coordinate) {                       // what `samtools sort` records in the header
-        if (text.compare(0, 3, "@HD") == 0) {
-            const size_t e = text.find('\n');
-            std::string hd = text.substr(0, e);
-            const size_t so = hd.find("\tSO:");
-            if (so != std::string::npos) { size_t q = hd.find('\t', so + 1); hd.erase(so, (q == std::string::npos ? hd.size() : q) - so); }
-            hd += "\tSO:coordinate";
-            text = hd + text.substr(e);
-        } else text = "@HD\tVN:1.6\tSO:coordinate\n" + text;
-    }
-    // ---- records, encoded in parallel over ranges of whole lines
+    // records, encoded in parallel over ranges of whole lines
     std::vector<size_t> cut(1, body);
     for (int t = 1; t < threads; ++t) {
         size_t at = body + (n - body) / (size_t)threads * (size_t)t;
@@ -241,10 +247,10 @@ void sam_to_bam(const char *sam_path, const char *bam_path, int min_mapq, bool s
     }
     cut.push_back(n);
     const int parts = (int)cut.size() - 1;
-    std::vector<std::string> enc((size_t)parts); std::vector<std::vector<Rec>> recs((size_t)parts);
+    d.enc.assign((size_t)parts, std::string()); std::vector<std::vector<Rec>> recs((size_t)parts);
     std::vector<uint64_t> n_in((size_t)parts, 0);
     par(parts, threads, [&](int t) {
-        std::string &o = enc[t]; o.reserve((cut[t + 1] - cut[t]));
+        std::string &o = d.enc[t]; o.reserve((cut[t + 1] - cut[t]));
         size_t i = cut[t];
         while (i < cut[t + 1]) {
             const char *e = (const char *)std::memchr(b + i, '\n', cut[t + 1] - i);
@@ -258,31 +264,182 @@ void sam_to_bam(const char *sam_path, const char *bam_path, int min_mapq, bool s
             i = j + 1;
         }
     });
-    std::vector<Rec> all; uint64_t total_in = 0;
-    { size_t m = 0; for (auto &v : recs) m += v.size(); all.reserve(m); for (int t = 0; t < parts; ++t) { all.insert(all.end(), recs[t].begin(), recs[t].end()); total_in += n_in[t]; } }
-    buf.clear(); buf.shrink_to_fit();
-    if (sort_by_coordinate)
-        std::stable_sort(all.begin(), all.end(), [](const Rec &x, const Rec &y) {
-            const uint32_t a = (uint32_t)x.ref, c = (uint32_t)y.ref;      // -1 (no reference) sorts last
-            return a != c ? a < c : x.pos < y.pos;
-        });
-    // ---- uncompressed stream: header (own blocks, as samtools flushes after it), then the records
+    size_t m = 0; for (auto &v : recs) m += v.size();
+    d.recs.reserve(m);
+    for (int t = 0; t < parts; ++t) { d.recs.insert(d.recs.end(), recs[t].begin(), recs[t].end()); d.n_in += n_in[t]; }
+}
+
+// ---- BGZF file -> uncompressed bytes; block starts (compressed offset, uncompressed offset)
+struct Blocks { std::string data; std::vector<std::pair<uint64_t, uint64_t>> starts; uint64_t file_bytes = 0; };
+static void inflate_bgzf(const char *path, int threads, Blocks &out)
+{
+    FILE *f = std::fopen(path, "rb");
+    if (!f) throw Err(std::string("cannot open ") + path);
+    std::fseek(f, 0, SEEK_END); const long sz = std::ftell(f); std::fseek(f, 0, SEEK_SET);
+    std::vector<unsigned char> raw((size_t)sz);
+    if (sz && std::fread(raw.data(), 1, (size_t)sz, f) != (size_t)sz) { std::fclose(f); throw Err(std::string("short read on ") + path); }
+    std::fclose(f);
+    out.file_bytes = (uint64_t)sz;
+    struct B { size_t at, bsize; uint32_t isize; uint64_t u; };
+    std::vector<B> bl; size_t at = 0; uint64_t u = 0;
+    while (at < raw.size()) {
+        if (at + 28 > raw.size() || raw[at] != 31 || raw[at + 1] != 139 || raw[at + 12] != 'B' || raw[at + 13] != 'C') throw Err(std::string("not a BGZF file: ") + path);
+        const size_t bsize = (size_t)(raw[at + 16] | (raw[at + 17] << 8)) + 1;
+        if (at + bsize > raw.size()) throw Err(std::string("truncated BGZF block in ") + path);
+        const unsigned char *t = raw.data() + at + bsize - 4;
+        const uint32_t isize = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+        bl.push_back(B{at, bsize, isize, u});
+        u += isize; at += bsize;
+    }
+    out.data.assign((size_t)u, '\0');
+    out.starts.clear();
+    for (const B &b : bl) out.starts.emplace_back((uint64_t)b.at, b.u);
+    const int T = threads;
+    par(T, T, [&](int t) {
+        for (size_t k = (size_t)t; k < bl.size(); k += (size_t)T) {
+            const B &b = bl[k];
+            if (!b.isize) continue;
+            z_stream zs; std::memset(&zs, 0, sizeof zs);
+            if (inflateInit2(&zs, -15) != Z_OK) throw Err("inflateInit2 failed");
+            zs.next_in = raw.data() + b.at + 18; zs.avail_in = (uInt)(b.bsize - 26);
+            zs.next_out = (Bytef *)&out.data[(size_t)b.u]; zs.avail_out = b.isize;
+            const int rc = inflate(&zs, Z_FINISH);
+            inflateEnd(&zs);
+            if (rc != Z_STREAM_END || zs.total_out != b.isize) throw Err(std::string("corrupt BGZF block in ") + path);
+        }
+    });
+}
+static uint32_t rd32(const std::string &s, size_t at) { const unsigned char *p = (const unsigned char *)s.data() + at; return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+
+// ---- BAM file -> Data (records stay as they are; their place in the file is kept for indexing)
+static void load_bam(const char *path, int threads, Data &d, Blocks *keep_blocks, std::vector<uint64_t> *rec_u)
+{
+    Blocks local; Blocks &bk = keep_blocks ? *keep_blocks : local;
+    inflate_bgzf(path, threads, bk);
+    const std::string &s = bk.data;
+    if (s.size() < 12 || s.compare(0, 4, "BAM\1") != 0) throw Err(std::string("not a BAM file: ") + path);
+    const uint32_t l_text = rd32(s, 4);
+    d.text = s.substr(8, l_text);
+    while (!d.text.empty() && d.text.back() == '\0') d.text.pop_back();
+    size_t at = 8 + (size_t)l_text;
+    const uint32_t n_ref = rd32(s, at); at += 4;
+    for (uint32_t r = 0; r < n_ref; ++r) {
+        const uint32_t ln = rd32(s, at);
+        d.refs.emplace_back(s.substr(at + 4, ln ? ln - 1 : 0), rd32(s, at + 4 + ln));
+        at += 8 + (size_t)ln;
+    }
+    d.enc.assign(1, std::string());
+    d.enc[0].assign(s, at, std::string::npos);
+    const std::string &e = d.enc[0];
+    const size_t base_u = at;
+    size_t p = 0;
+    while (p + 4 <= e.size()) {
+        const uint32_t bs = rd32(e, p);
+        if (bs < 32 || p + 4 + bs > e.size()) throw Err(std::string("corrupt BAM record in ") + path);
+        Rec r; r.part = 0; r.off = p; r.len = 4 + (size_t)bs;
+        r.ref = (int32_t)rd32(e, p + 4); r.pos = (int32_t)rd32(e, p + 8);
+        const uint32_t w = rd32(e, p + 12), fl = rd32(e, p + 16);
+        const uint32_t l_name = w & 0xff, n_cig = fl & 0xffff;
+        r.flag = fl >> 16;
+        int64_t ref_len = 0;
+        const size_t cig_at = p + 36 + l_name;
+        for (uint32_t c = 0; c < n_cig; ++c) { const uint32_t v = rd32(e, cig_at + 4 * c); const int op = (int)(v & 15); if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += v >> 4; }
+        r.end = (int32_t)(r.pos + (ref_len > 0 ? ref_len : 1));
+        d.recs.push_back(r);
+        if (rec_u) rec_u->push_back((uint64_t)(base_u + p));
+        p += 4 + bs;
+    }
+    d.n_in = d.recs.size();
+    if (!keep_blocks) { bk.data.clear(); bk.data.shrink_to_fit(); }
+}
+static int rec_mapq(const Data &d, const Rec &r) { return (int)((rd32(d.enc[r.part], r.off + 12) >> 8) & 0xff); }
+static const char *rec_name(const Data &d, const Rec &r) { return d.enc[r.part].data() + r.off + 36; }
+
+// read names as `samtools sort -n` orders them: digit runs compare as numbers
+static int strnum_cmp(const char *a, const char *b)
+{
+    const unsigned char *pa = (const unsigned char *)a, *pb = (const unsigned char *)b;
+    while (*pa && *pb) {
+        if (std::isdigit(*pa) && std::isdigit(*pb)) {
+            while (*pa == '0') ++pa;
+            while (*pb == '0') ++pb;
+            const unsigned char *ea = pa, *eb = pb;
+            while (std::isdigit(*ea)) ++ea;
+            while (std::isdigit(*eb)) ++eb;
+            if (ea - pa != eb - pb) return (ea - pa) < (eb - pb) ? -1 : 1;
+            for (; pa < ea; ++pa, ++pb) if (*pa != *pb) return *pa < *pb ? -1 : 1;
+        } else {
+            if (*pa != *pb) return *pa < *pb ? -1 : 1;
+            ++pa; ++pb;
+        }
+    }
+    return *pa ? 1 : (*pb ? -1 : 0);
+}
+
+// virtual offsets of the records of an existing layout, then the .bai
+struct Layout { std::vector<uint64_t> vbeg, vend; };
+static void write_bai(const std::string &bai_path, const Data &d, const Layout &lay)
+{
+    struct RefIdx { std::map<uint32_t, std::vector<std::pair<uint64_t, uint64_t>>> bins; std::vector<uint64_t> lin; uint64_t beg = 0, end = 0, n_map = 0, n_unmap = 0; bool any = false; };
+    std::vector<RefIdx> idx(d.refs.size());
+    uint64_t n_no_coor = 0;
+    for (size_t i = 0; i < d.recs.size(); ++i) {
+        const Rec &r = d.recs[i];
+        if (r.ref < 0) { ++n_no_coor; continue; }
+        if ((size_t)r.ref >= idx.size()) throw Err("record refers to a reference that is not in the header");
+        RefIdx &x = idx[(size_t)r.ref];
+        const uint64_t vb = lay.vbeg[i], ve = lay.vend[i];
+        if (!x.any) { x.beg = vb; x.any = true; }
+        x.end = ve;
+        if (r.flag & 4) ++x.n_unmap; else ++x.n_map;
+        const uint32_t bin = (uint32_t)reg2bin(r.pos, r.end);
+        auto &ch = x.bins[bin];
+        if (!ch.empty() && (ch.back().second >> 16 == vb >> 16 || ch.back().second == vb)) ch.back().second = ve;     // same compressed block or adjacent: extend
+        else ch.emplace_back(vb, ve);
+        const size_t w0 = (size_t)(r.pos >> 14), w1 = (size_t)((r.end - 1) >> 14);
+        if (x.lin.size() <= w1) x.lin.resize(w1 + 1, 0);
+        for (size_t w = w0; w <= w1; ++w) if (x.lin[w] == 0) x.lin[w] = vb;
+    }
+    std::string bai;
+    bai.append("BAI\1", 4); put32(bai, (uint32_t)d.refs.size());
+    for (RefIdx &x : idx) {
+        put32(bai, (uint32_t)(x.bins.size() + (x.any ? 1 : 0)));
+        for (auto &kv : x.bins) {
+            put32(bai, kv.first); put32(bai, (uint32_t)kv.second.size());
+            for (auto &c : kv.second) { put64(bai, c.first); put64(bai, c.second); }
+        }
+        if (x.any) { put32(bai, 37450u); put32(bai, 2u); put64(bai, x.beg); put64(bai, x.end); put64(bai, x.n_map); put64(bai, x.n_unmap); }
+        for (size_t w = 1; w < x.lin.size(); ++w) if (x.lin[w] == 0) x.lin[w] = x.lin[w - 1];
+        put32(bai, (uint32_t)x.lin.size());
+        for (uint64_t v : x.lin) put64(bai, v);
+    }
+    put64(bai, n_no_coor);
+    FILE *bi = std::fopen(bai_path.c_str(), "wb");
+    if (!bi) throw Err("cannot write " + bai_path);
+    bool ok = std::fwrite(bai.data(), 1, bai.size(), bi) == bai.size();
+    ok = (std::fclose(bi) == 0) && ok;
+    if (!ok) throw Err("short write on " + bai_path);
+}
+
+// ---- Data (records in d.recs order) -> BGZF file (+ .bai)
+static void write_bam(Data &d, const char *bam_path, bool write_index, int threads, BamStats *stats)
+{
     std::string head;
-    head.append("BAM\1", 4); put32(head, (uint32_t)text.size()); head += text; put32(head, (uint32_t)refs.size());
-    for (auto &r : refs) { put32(head, (uint32_t)r.first.size() + 1); head += r.first; head.push_back('\0'); put32(head, r.second); }
+    head.append("BAM\1", 4); put32(head, (uint32_t)d.text.size()); head += d.text; put32(head, (uint32_t)d.refs.size());
+    for (auto &r : d.refs) { put32(head, (uint32_t)r.first.size() + 1); head += r.first; head.push_back('\0'); put32(head, r.second); }
     const size_t BLK = 0xff00;
-    const size_t head_blocks = (head.size() + BLK - 1) / BLK;
+    const size_t head_blocks = (head.size() + BLK - 1) / BLK;           // own blocks: samtools flushes after the header too
+    const std::vector<Rec> &all = d.recs;
     std::vector<uint64_t> uoff(all.size() + 1, 0);
     for (size_t i = 0; i < all.size(); ++i) uoff[i + 1] = uoff[i] + all[i].len;
     const uint64_t body_bytes = uoff[all.size()];
     const size_t body_blocks = (size_t)((body_bytes + BLK - 1) / BLK);
-    // gather the body in final order (parallel copy), then compress block by block
     std::string stream((size_t)body_bytes, '\0');
     {
         const int T = threads; const size_t per = (all.size() + (size_t)T - 1) / (size_t)T;
-        par(T, T, [&](int t) { const size_t a0 = (size_t)t * per, a1 = std::min(all.size(), a0 + per); for (size_t i = a0; i < a1; ++i) std::memcpy(&stream[(size_t)uoff[i]], enc[all[i].part].data() + all[i].off, all[i].len); });
+        par(T, T, [&](int t) { const size_t a0 = (size_t)t * per, a1 = std::min(all.size(), a0 + per); for (size_t i = a0; i < a1; ++i) std::memcpy(&stream[(size_t)uoff[i]], d.enc[all[i].part].data() + all[i].off, all[i].len); });
     }
-    for (auto &e : enc) { e.clear(); e.shrink_to_fit(); }
+    for (auto &e : d.enc) { e.clear(); e.shrink_to_fit(); }
     const size_t n_blocks = head_blocks + body_blocks;
     std::vector<std::string> comp(n_blocks);
     {
@@ -304,54 +461,97 @@ void sam_to_bam(const char *sam_path, const char *bam_path, int min_mapq, bool s
     ok = ok && std::fwrite(eof_block, 1, 28, o) == 28;
     ok = (std::fclose(o) == 0) && ok;
     if (!ok) throw Err(std::string("short write on ") + bam_path);
-    auto voff = [&](uint64_t u) -> uint64_t {           // virtual file offset of body byte u
-        const uint64_t k = u / BLK;
-        if (u == body_bytes && u % BLK == 0) return (coff[n_blocks]) << 16;     // end of the last full block = start of the EOF block
-        return (coff[head_blocks + (size_t)k] << 16) | (u % BLK);
-    };
-    if (stats) { stats->n_in = total_in; stats->n_out = all.size(); stats->bam_bytes = coff[n_blocks] + 28; }
+    if (stats) { stats->n_in = d.n_in; stats->n_out = all.size(); stats->bam_bytes = coff[n_blocks] + 28; }
     if (!write_index) return;
-    // ---- .bai: binning index + 16 kb linear index per reference (SAMv1 §5.2)
-    struct RefIdx { std::map<uint32_t, std::vector<std::pair<uint64_t, uint64_t>>> bins; std::vector<uint64_t> lin; uint64_t beg = 0, end = 0, n_map = 0, n_unmap = 0; bool any = false; };
-    std::vector<RefIdx> idx(refs.size());
-    uint64_t n_no_coor = 0;
-    for (size_t i = 0; i < all.size(); ++i) {
-        const Rec &r = all[i];
-        if (r.ref < 0) { ++n_no_coor; continue; }
-        RefIdx &x = idx[(size_t)r.ref];
-        const uint64_t vb = voff(uoff[i]), ve = voff(uoff[i + 1]);
-        if (!x.any) { x.beg = vb; x.any = true; }
-        x.end = ve;
-        if (r.flag & 4) ++x.n_unmap; else ++x.n_map;
-        const uint32_t bin = (uint32_t)reg2bin(r.pos, r.end);
-        auto &ch = x.bins[bin];
-        if (!ch.empty() && ch.back().second >> 16 == vb >> 16) ch.back().second = ve;      // same compressed block: extend
-        else if (!ch.empty() && ch.back().second == vb) ch.back().second = ve;
-        else ch.emplace_back(vb, ve);
-        const size_t w0 = (size_t)(r.pos >> 14), w1 = (size_t)((r.end - 1) >> 14);
-        if (x.lin.size() <= w1) x.lin.resize(w1 + 1, 0);
-        for (size_t w = w0; w <= w1; ++w) if (x.lin[w] == 0) x.lin[w] = vb;
+    auto voff = [&](uint64_t u) -> uint64_t {           // virtual file offset of body byte u
+        if (u == body_bytes && u % BLK == 0) return coff[n_blocks] << 16;      // end of the last full block = start of the EOF block
+        return (coff[head_blocks + (size_t)(u / BLK)] << 16) | (u % BLK);
+    };
+    Layout lay; lay.vbeg.resize(all.size()); lay.vend.resize(all.size());
+    for (size_t i = 0; i < all.size(); ++i) { lay.vbeg[i] = voff(uoff[i]); lay.vend[i] = voff(uoff[i + 1]); }
+    write_bai(std::string(bam_path) + ".bai", d, lay);
+}
+
+static void sort_records(Data &d, bool by_name)
+{
+    if (by_name)
+        std::stable_sort(d.recs.begin(), d.recs.end(), [&](const Rec &x, const Rec &y) {
+            const int c = strnum_cmp(rec_name(d, x), rec_name(d, y));
+            if (c) return c < 0;
+            return ((x.flag >> 6) & 3) < ((y.flag >> 6) & 3);             // first of pair before second
+        });
+    else
+        std::stable_sort(d.recs.begin(), d.recs.end(), [](const Rec &x, const Rec &y) {
+            const uint32_t a = (uint32_t)x.ref, c = (uint32_t)y.ref;      // -1 (no reference) sorts last
+            return a != c ? a < c : x.pos < y.pos;
+        });
+}
+
+}  // namespace
+
+static int clamp_threads(int t) { return t < 1 ? 1 : (t > 64 ? 64 : t); }
+
+void sam_to_bam(const char *sam_path, const char *bam_path, int min_mapq, bool sort_by_coordinate, bool write_index, int threads, BamStats *stats)
+{
+    threads = clamp_threads(threads);
+    if (write_index && !sort_by_coordinate) throw Err("a .bai index needs coordinate-sorted output");
+    Data d;
+    load_sam(sam_path, min_mapq, threads, d);
+    if (sort_by_coordinate) { header_sorted(d.text, "coordinate"); sort_records(d, false); }
+    write_bam(d, bam_path, write_index, threads, stats);
+}
+
+// `samtools view -q <mapq> -b in.bam -o out.bam`
+void bam_view(const char *in_bam, const char *out_bam, int min_mapq, int threads, BamStats *stats)
+{
+    threads = clamp_threads(threads);
+    Data d;
+    load_bam(in_bam, threads, d, nullptr, nullptr);
+    if (min_mapq > 0) {
+        std::vector<Rec> keep; keep.reserve(d.recs.size());
+        for (const Rec &r : d.recs) if (rec_mapq(d, r) >= min_mapq) keep.push_back(r);
+        d.recs.swap(keep);
     }
-    std::string bai;
-    bai.append("BAI\1", 4); put32(bai, (uint32_t)refs.size());
-    for (RefIdx &x : idx) {
-        put32(bai, (uint32_t)(x.bins.size() + (x.any ? 1 : 0)));
-        for (auto &kv : x.bins) {
-            put32(bai, kv.first); put32(bai, (uint32_t)kv.second.size());
-            for (auto &c : kv.second) { put64(bai, c.first); put64(bai, c.second); }
-        }
-        if (x.any) { put32(bai, 37450u); put32(bai, 2u); put64(bai, x.beg); put64(bai, x.end); put64(bai, x.n_map); put64(bai, x.n_unmap); }
-        for (size_t w = 1; w < x.lin.size(); ++w) if (x.lin[w] == 0) x.lin[w] = x.lin[w - 1];
-        put32(bai, (uint32_t)x.lin.size());
-        for (uint64_t v : x.lin) put64(bai, v);
+    write_bam(d, out_bam, false, threads, stats);
+}
+
+// `samtools sort [-n] in.bam -o out.bam`
+void bam_sort(const char *in_bam, const char *out_bam, bool by_name, int threads, BamStats *stats)
+{
+    threads = clamp_threads(threads);
+    Data d;
+    load_bam(in_bam, threads, d, nullptr, nullptr);
+    header_sorted(d.text, by_name ? "queryname" : "coordinate");
+    sort_records(d, by_name);
+    write_bam(d, out_bam, false, threads, stats);
+}
+
+// `samtools index in.bam`: <in.bam>.bai for a coordinate-sorted file, the file itself is not rewritten
+void bam_index(const char *bam, int threads)
+{
+    threads = clamp_threads(threads);
+    Data d; Blocks bk; std::vector<uint64_t> rec_u;
+    load_bam(bam, threads, d, &bk, &rec_u);
+    for (size_t i = 1; i < d.recs.size(); ++i) {
+        const uint32_t a = (uint32_t)d.recs[i - 1].ref, c = (uint32_t)d.recs[i].ref;
+        if (a > c || (a == c && d.recs[i - 1].pos > d.recs[i].pos)) throw Err(std::string("not sorted by coordinate: ") + bam);
     }
-    put64(bai, n_no_coor);
-    const std::string bai_path = std::string(bam_path) + ".bai";
-    FILE *bi = std::fopen(bai_path.c_str(), "wb");
-    if (!bi) throw Err("cannot write " + bai_path);
-    ok = std::fwrite(bai.data(), 1, bai.size(), bi) == bai.size();
-    ok = (std::fclose(bi) == 0) && ok;
-    if (!ok) throw Err("short write on " + bai_path);
+    auto voff = [&](uint64_t u) -> uint64_t {           // uncompressed offset -> (compressed block start << 16) | offset inside
+        size_t lo = 0, hi = bk.starts.size();
+        while (hi - lo > 1) { const size_t mid = (lo + hi) / 2; if (bk.starts[mid].second <= u) lo = mid; else hi = mid; }
+        // an offset that is exactly a block boundary belongs to the start of the later block (skip empty blocks except the last)
+        return (bk.starts[lo].first << 16) | (u - bk.starts[lo].second);
+    };
+    const uint64_t total = bk.data.size();
+    auto voff_end = [&](uint64_t u) -> uint64_t {       // the end of the data is "the last data block, past its last byte"
+        if (u < total || u == 0) return voff(u);
+        size_t lo = 0, hi = bk.starts.size();
+        while (hi - lo > 1) { const size_t mid = (lo + hi) / 2; if (bk.starts[mid].second <= u - 1) lo = mid; else hi = mid; }
+        return (bk.starts[lo].first << 16) | (u - bk.starts[lo].second);
+    };
+    Layout lay; lay.vbeg.resize(d.recs.size()); lay.vend.resize(d.recs.size());
+    for (size_t i = 0; i < d.recs.size(); ++i) { lay.vbeg[i] = voff(rec_u[i]); lay.vend[i] = voff_end(rec_u[i] + d.recs[i].len); }
+    write_bai(std::string(bam) + ".bai", d, lay);
 }
 
 }  // namespace ps

@@ -390,4 +390,27 @@ int ps_sam_to_bam(const char *sam, const char *bam, int min_mapq, int sort_by_co
     PS_CATCH_INT
 }
 
+int ps_bam_view(const char *in_bam, const char *out_bam, int min_mapq, int threads, ps_bam_stats *st)
+{
+    PS_TRY
+        BamStats s; bam_view(in_bam, out_bam, min_mapq, threads, &s);
+        if (st) { st->n_in = s.n_in; st->n_out = s.n_out; st->bam_bytes = s.bam_bytes; }
+        return 0;
+    PS_CATCH_INT
+}
+int ps_bam_sort(const char *in_bam, const char *out_bam, int by_name, int threads, ps_bam_stats *st)
+{
+    PS_TRY
+        BamStats s; bam_sort(in_bam, out_bam, by_name != 0, threads, &s);
+        if (st) { st->n_in = s.n_in; st->n_out = s.n_out; st->bam_bytes = s.bam_bytes; }
+        return 0;
+    PS_CATCH_INT
+}
+int ps_bam_index(const char *bam, int threads)
+{
+    PS_TRY
+        bam_index(bam, threads); return 0;
+    PS_CATCH_INT
+}
+
 }  // extern "C"

@@ -259,3 +259,73 @@ def test_errors_are_reported(tmp_path):
         capi.ps_sam_to_bam(str(bad), str(tmp_path / "bad.bam"))
     with pytest.raises(capi.PsError):
         capi.ps_sam_to_bam(str(tmp_path / "missing.sam"), str(tmp_path / "x.bam"))
+
+
+# ---------------------------------------------------------------- the same steps on BAM input, and the argv shim ---------
+def _natural_key(name):
+    """samtools' strnum_cmp: digit runs compare as numbers"""
+    import re
+    return [(1, int(t), 0) if t.isdigit() else (0, 0, t) for t in re.findall(r"\d+|\D", name)]
+
+
+def test_steps_on_bam_input(sam, tmp_path):
+    """view -q, sort, sort -n, index as separate calls on BAM files -- the sequence the unmodified Java issues"""
+    import capi
+    _, srecs = sam_fields(sam)
+    a, q, s, n = (str(tmp_path / x) for x in ("a.bam", "q.bam", "s.bam", "n.bam"))
+    capi.ps_sam_to_bam(sam, a, threads=4)
+    st = capi.ps_bam_view(a, q, min_mapq=10, threads=4)
+    keep = [f for f in srecs if int(f[4]) >= 10]
+    text, refs, recs, _ = read_bam(q)
+    assert st["n_in"] == len(srecs) and st["n_out"] == len(keep)
+    _check_records(keep, recs, refs)                                          # records pass through byte for byte
+    capi.ps_bam_sort(q, s, threads=4)
+    text, refs, recs, starts = read_bam(s)
+    assert text.split("\n")[0].endswith("SO:coordinate")
+    key = [((r["ref"] & 0xffffffff), r["pos"]) for r in recs]
+    assert key == sorted(key) and len(recs) == len(keep)
+    # one-call and step-by-step pipelines give the same file
+    one = str(tmp_path / "one.bam")
+    capi.ps_sam_to_bam(sam, one, min_mapq=10, sort_by_coordinate=True, write_index=True, threads=4)
+    assert read_bam(one)[2] == recs
+    capi.ps_bam_index(s, threads=4)
+    assert open(s + ".bai", "rb").read() == open(one + ".bai", "rb").read() or read_bai(s + ".bai")[0] == read_bai(one + ".bai")[0]
+    # index of an existing file: offsets must point into THAT file
+    idx, _ = read_bai(s + ".bai")
+    for tid in range(len(refs)):
+        for b, chunks in idx[tid][0].items():
+            if b == 37450:
+                continue
+            for cb, ce in chunks:
+                u0 = voffset_to_u(starts, cb)
+                assert any(r["u0"] == u0 for r in recs)                       # every chunk starts at a record
+    with pytest.raises(capi.PsError):
+        capi.ps_bam_index(q)                                                  # not coordinate-sorted
+    capi.ps_bam_sort(q, n, by_name=True, threads=4)
+    text, _, nrecs, _ = read_bam(n)
+    assert text.split("\n")[0].endswith("SO:queryname")
+    names = [r["name"] for r in nrecs]
+    assert names == sorted(names, key=_natural_key) and sorted(names) == sorted(f[0] for f in keep)
+
+
+def test_samtools_argv_shim(sam, tmp_path):
+    """para-suite_amd/bin/samtools accepts the four command lines of PARAsuiteMapping.java:102-133 / Mapping.java:85-105"""
+    import subprocess
+    exe = os.path.join(ROOT, "para-suite_amd", "bin", "samtools")
+    assert os.path.exists(exe), "run the build first"
+    p = str(tmp_path / "P")
+    import shutil
+    shutil.copy(sam, p + ".sam")
+    run = lambda *a: subprocess.run([exe] + list(a), stderr=subprocess.PIPE, stdout=subprocess.PIPE)
+    assert run("view", "-bS", "-t", "ref.fa", p + ".sam", "-o", p + ".bam").returncode == 0
+    assert run("view", "-q", "10", "-b", p + ".bam", "-o", p + ".unique.bam").returncode == 0
+    assert run("sort", p + ".unique.bam", "-o", p + ".unique.bamsort.bam").returncode == 0
+    os.replace(p + ".unique.bamsort.bam", p + ".unique.bam")
+    assert run("index", p + ".unique.bam").returncode == 0
+    _, srecs = sam_fields(sam)
+    _, refs, recs, _ = read_bam(p + ".unique.bam")
+    assert len(recs) == sum(int(f[4]) >= 10 for f in srecs) and os.path.getsize(p + ".unique.bam.bai") > 8
+    r = run("mpileup", p + ".bam")
+    assert r.returncode == 1 and b"not supported" in r.stderr
+    r = run("view", "-q", "10", "-b", p + ".nope.bam", "-o", p + ".x.bam")
+    assert r.returncode == 1
