@@ -2,7 +2,7 @@
 
 Each case draws a genome shape (plain / repeats / low complexity / tiny), a read length, a cost model (stock -n or a
 random error profile with -X) and read noise (substitutions, indels, N's), maps a few thousand reads both ways and stops at
-the first difference.  usage: python tools/fuzz_parity.py [n_cases] [seed]"""
+the first difference.  usage: python tests/fuzz_parity.py [n_cases] [seed]"""
 import os
 import sys
 import tempfile

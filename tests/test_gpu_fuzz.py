@@ -1,4 +1,4 @@
-"""Randomised parity on the GPU (tools/fuzz_parity.py): genome shape x read length x cost model x noise x tier sizes, the
+"""Randomised parity on the GPU (tests/fuzz_parity.py): genome shape x read length x cost model x noise x tier sizes, the
 product through the C ABI against the CPU oracle, SAM line by line and hit-list lengths.  600 such cases were run when
 this was written (seeds 2-5, 150 cases each: all identical); the test keeps a 30-case sample in the suite."""
 import os
@@ -6,7 +6,7 @@ import sys
 
 import pytest
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
