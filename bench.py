@@ -162,7 +162,7 @@ def main():
     ap.add_argument("--genome-mbp", type=int, default=3100)
     ap.add_argument("--contigs", type=int, default=24)
     ap.add_argument("--workload", choices=["full", "exact"], default="full")
-    ap.add_argument("--cpu-sample", type=int, default=40000, help="reads of the same workload timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=250000, help="reads of the same workload timed on the CPU oracle (0 = skip)")
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--penalty", choices=["profile", "stock"], default="profile", help="full workload: PAR-CLIP error-profile costs (bwa parasuite) or stock costs (bwa aln -n 0.04)")
     ap.add_argument("--keep", default="")
