@@ -350,14 +350,16 @@ int ps_map(int threads, const char *mm, const char *error_profile, const char *i
                 const auto t0 = std::chrono::steady_clock::now();
                 n_reads += rs.n; ++n_pieces;
                 std::unique_ptr<Batch> b = batch_create(&x->c, std::move(rs));
+                const double w_create = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
                 batch_search(*b);
+                const double w_search = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() - w_create;
                 batch_select_hard(*b, draws, &draws);
                 batch_select_easy(*b, nthr);
                 batch_locate(*b);
                 if (verbose) {
                     const Timing &t = b->tm;
-                    std::fprintf(stderr, "[parasuite-hip]   piece %d: %lld reads; width %.0f backtrack %.0f classify %.0f select %.0f+%.0f sa2pos %.0f refine %.0f host_post %.0f ms\n",
-                                 n_pieces, (long long)b->rs.n, t.ms_width, t.ms_backtrack, t.ms_classify, t.ms_sel_hard, t.ms_sel_easy, t.ms_sa2pos, t.ms_refine, t.ms_host_post);
+                    std::fprintf(stderr, "[parasuite-hip]   piece %d: %lld reads; pack+upload %.0f ms, search stage %.0f ms wall (width %.0f backtrack %.0f classify %.0f), select %.0f+%.0f sa2pos %.0f refine %.0f host_post %.0f ms\n",
+                                 n_pieces, (long long)b->rs.n, 1e3 * w_create, 1e3 * w_search, t.ms_width, t.ms_backtrack, t.ms_classify, t.ms_sel_hard, t.ms_sel_easy, t.ms_sa2pos, t.ms_refine, t.ms_host_post);
                 }
                 t_gpu += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
                 header_only = false;
