@@ -1,6 +1,7 @@
 """Randomised parity on the GPU (tests/fuzz_parity.py): genome shape x read length x cost model x noise x tier sizes, the
-product through the C ABI against the CPU oracle, SAM line by line and hit-list lengths.  600 such cases were run when
-this was written (seeds 2-5, 150 cases each: all identical); the test keeps a 30-case sample in the suite."""
+product through the C ABI against the CPU oracle, SAM line by line and hit-list lengths.  1,960 such cases were run in round 1
+(seeds 1-5, 21, 101-108: all identical, including ragged lengths after reads of one cost class began to share a launch);
+the test keeps a 30-case sample in the suite."""
 import os
 import sys
 
