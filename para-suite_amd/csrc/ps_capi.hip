@@ -299,16 +299,20 @@ int ps_map(int threads, const char *mm, const char *error_profile, const char *i
         const int nthr = threads > 0 ? threads : 1;
         size_t chunk_bytes = (size_t)400 << 20;
         if (const char *e = std::getenv("PS_CHUNK_MB")) chunk_bytes = (size_t)std::max(1, std::atoi(e)) << 20;
-        Chan<ReadSet> parsed; Chan<std::unique_ptr<Batch>> mapped;
+        Chan<std::unique_ptr<Batch>> parsed, mapped;
+        // the context (stream, options) exists before the index is loaded: the parser stage needs the cost model to bin
+        // and pack the reads, not the index
+        ps_ctx *x = new_ctx(0);
+        if (error_profile && error_profile[0] ? ps_ctx_set_profile(x, error_profile, indel_profile, mm)
+                                               : ps_ctx_set_stock(x, mm && mm[0] ? mm : "0.04")) { const std::string m = g_err; ps_ctx_close(x); return fail(m); }
+        x->c.host_threads = nthr;
         std::exception_ptr perr, werr;
         double t_parse = 0, t_write = 0;
         // ---- stage 1: parser (starts at once; the file is read whole, then parsed piece by piece)
         std::thread parser([&]() {
             try {
                 load_reads_chunked(fastq, std::max(1, nthr / 2), chunk_bytes, [&](ReadSet &&rs) {
-                    const auto t0 = std::chrono::steady_clock::now();
-                    parsed.push(std::move(rs));
-                    (void)t0;
+                    parsed.push(batch_prepare(&x->c, std::move(rs), std::max(1, nthr / 2)));     // bins, order, 2-bit packing: host only
                 });
                 t_parse = since();
             } catch (...) { perr = std::current_exception(); }
@@ -333,23 +337,19 @@ int ps_map(int threads, const char *mm, const char *error_profile, const char *i
         });
         // ---- stage 2: this thread
         int rc = 0; std::string msg;
-        ps_ctx *x = nullptr;
         double t_index = 0, t_gpu = 0; int64_t n_reads = 0; int n_pieces = 0;
         try {
-            x = index_files_exist(ref_fa) ? ps_ctx_open(ref_fa, 0) : ps_ctx_build(ref_fa, 0, 1);
-            if (!x) throw Error(g_err);
-            t_index = since();
-            if (error_profile && error_profile[0] ? ps_ctx_set_profile(x, error_profile, indel_profile, mm)
-                                                   : ps_ctx_set_stock(x, mm && mm[0] ? mm : "0.04")) throw Error(g_err);
-            x->c.host_threads = nthr;
             require_device(x->c.device);
+            if (index_files_exist(ref_fa)) index_load(ref_fa, x->c.ix, x->c.stream);
+            else { index_build(ref_fa, x->c.ix, x->c.stream); index_save(x->c.ix, ref_fa); }
+            t_index = since();
             uint64_t draws = 0;
-            ReadSet rs;
+            std::unique_ptr<Batch> b;
             bool header_only = true;
-            while (parsed.pop(rs)) {
+            while (parsed.pop(b)) {
                 const auto t0 = std::chrono::steady_clock::now();
-                n_reads += rs.n; ++n_pieces;
-                std::unique_ptr<Batch> b = batch_create(&x->c, std::move(rs));
+                n_reads += b->rs.n; ++n_pieces;
+                batch_upload(*b);
                 const double w_create = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
                 batch_search(*b);
                 const double w_search = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() - w_create;
@@ -358,7 +358,7 @@ int ps_map(int threads, const char *mm, const char *error_profile, const char *i
                 batch_locate(*b);
                 if (verbose) {
                     const Timing &t = b->tm;
-                    std::fprintf(stderr, "[parasuite-hip]   piece %d: %lld reads; pack+upload %.0f ms, search stage %.0f ms wall (width %.0f backtrack %.0f classify %.0f), select %.0f+%.0f sa2pos %.0f refine %.0f host_post %.0f ms\n",
+                    std::fprintf(stderr, "[parasuite-hip]   piece %d: %lld reads; upload %.0f ms, search stage %.0f ms wall (width %.0f backtrack %.0f classify %.0f), select %.0f+%.0f sa2pos %.0f refine %.0f host_post %.0f ms\n",
                                  n_pieces, (long long)b->rs.n, 1e3 * w_create, 1e3 * w_search, t.ms_width, t.ms_backtrack, t.ms_classify, t.ms_sel_hard, t.ms_sel_easy, t.ms_sa2pos, t.ms_refine, t.ms_host_post);
                 }
                 t_gpu += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -130,7 +130,9 @@ struct Batch {
     void hit_of(int64_t g, Hit &h) const;
 };
 
-std::unique_ptr<Batch> batch_create(Ctx *ctx, ReadSet &&rs);   // bins by length, packs 2-bit, uploads
+std::unique_ptr<Batch> batch_create(Ctx *ctx, ReadSet &&rs);   // bins by cost class, packs 2-bit, uploads (= prepare + upload)
+std::unique_ptr<Batch> batch_prepare(Ctx *ctx, ReadSet &&rs, int threads);   // host half: needs ctx->opt only, no device call
+void batch_upload(Batch &b);                                                  // device half
 void batch_search(Batch &b);                                    // width + backtracking kernels (+ larger tiers), hit lists to host
 void batch_select_hard(Batch &b, uint64_t draws_before, uint64_t *draws_after);
 void batch_select_easy(Batch &b, int threads);

@@ -219,12 +219,12 @@ void reads_from_codes(int64_t n, int len, const uint8_t *codes, ReadSet &rs)
 }
 
 // ------------------------------------------------------------ batch set-up ---
-std::unique_ptr<Batch> batch_create(Ctx *ctx, ReadSet &&rs_in)
+// host half of batch_create: bins, order inside the bins, 2-bit packing -- no device call, so the parser thread of
+// ps_map runs it while the GPU thread is busy with the piece before
+std::unique_ptr<Batch> batch_prepare(Ctx *ctx, ReadSet &&rs_in, int threads)
 {
     std::unique_ptr<Batch> b(new Batch());
     b->ctx = ctx; b->rs = std::move(rs_in);
-    b->wk = ctx->take_work();
-    Work *wk = b->wk;
     const ReadSet &rs = b->rs;
     // cost class of a length: everything of the search model that depends on the length except the length itself
     std::map<int, int> class_of_len;                     // length -> bin
@@ -277,7 +277,7 @@ std::unique_ptr<Batch> batch_create(Ctx *ctx, ReadSet &&rs_in)
         bin.n_bw = (bin.len + 15) / 16; bin.n_mw = (bin.len + 31) / 32;
         bin.h_bases.assign((size_t)bin.n_bw * n, 0); bin.h_nmask.assign((size_t)bin.n_mw * n, 0);
         {
-            const int nt = std::max(1, std::min(ctx->host_threads, 64));
+            const int nt = std::max(1, std::min(threads, 64));
             auto pack = [&](int t) {                                  // distinct reads write distinct words: no sharing
                 for (size_t r = n * t / nt; r < n * (t + 1) / nt; ++r) {
                     const uint8_t *s = rs.seq.data() + rs.off[bin.ids[r]];
@@ -295,6 +295,17 @@ std::unique_ptr<Batch> batch_create(Ctx *ctx, ReadSet &&rs_in)
         }
         bin.lens.resize(n);
         for (size_t r = 0; r < n; ++r) bin.lens[r] = rs.len[bin.ids[r]];
+    }
+    return b;
+}
+// device half: allocate and upload
+void batch_upload(Batch &bb)
+{
+    Batch *b = &bb; Ctx *ctx = b->ctx;
+    b->wk = ctx->take_work();
+    Work *wk = b->wk;
+    for (Bin &bin : b->bins) {
+        const size_t n = bin.ids.size();
         if (bin.ragged) { bin.d_lens.alloc(n); bin.d_lens.upload(bin.lens.data(), n, wk->stream); }
         bin.d_ids.alloc(n); bin.d_ids.upload(bin.ids.data(), n, wk->stream);
         bin.bases.alloc(bin.h_bases.size()); bin.nmask.alloc(bin.h_nmask.size());
@@ -303,6 +314,11 @@ std::unique_ptr<Batch> batch_create(Ctx *ctx, ReadSet &&rs_in)
     }
     b->d_stats.alloc(3);
     PS_HIP(hipStreamSynchronize(wk->stream));
+}
+std::unique_ptr<Batch> batch_create(Ctx *ctx, ReadSet &&rs_in)
+{
+    std::unique_ptr<Batch> b = batch_prepare(ctx, std::move(rs_in), ctx->host_threads);
+    batch_upload(*b);
     return b;
 }
 
