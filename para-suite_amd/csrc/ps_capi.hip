@@ -3,6 +3,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <deque>
+#include <map>
 #include <mutex>
 #include <thread>
 #include <cstdio>
@@ -285,10 +286,13 @@ int ps_batch_kstats(ps_batch *b, int which, ps_kstats *o)
     PS_CATCH_INT
 }
 
-// The whole `map` step behind one call.  Three stages run side by side on pieces of the input (whole records, about
-// PS_CHUNK_MB of FASTQ each, default 400): a parser thread, this thread driving the GPU (pack + upload, search, samse
-// stage; the tie-break stream position is carried from piece to piece), and a writer thread formatting SAM.  The
-// index is loaded while the parser already works.
+// The whole `map` step behind one call.  Stages run side by side on pieces of the input (whole records, about
+// PS_CHUNK_MB of FASTQ each, default 400): a parser thread (parse, bin, 2-bit pack), one GPU worker per device
+// (upload, search, samse stage) and a writer thread formatting SAM in input order.  Devices: the first
+// PARASUITE_GPUS devices (default 1), or the list in PARASUITE_GPU_IDS (a device may be named twice: rehearsal on one
+// GPU); every worker holds its own copy of the index.  Pieces go to whichever worker is free; the one sequential
+// thing, the tie-break stream, is handed from piece to piece in input order (only the reads whose draw count is data
+// dependent sit on that chain), so the SAM does not depend on the cut or on the number of devices.
 int ps_map(int threads, const char *mm, const char *error_profile, const char *indel_profile,
            const char *ref_fa, const char *fastq, const char *out_sam)
 {
@@ -299,85 +303,136 @@ int ps_map(int threads, const char *mm, const char *error_profile, const char *i
         const int nthr = threads > 0 ? threads : 1;
         size_t chunk_bytes = (size_t)400 << 20;
         if (const char *e = std::getenv("PS_CHUNK_MB")) chunk_bytes = (size_t)std::max(1, std::atoi(e)) << 20;
-        Chan<std::unique_ptr<Batch>> parsed, mapped;
-        // the context (stream, options) exists before the index is loaded: the parser stage needs the cost model to bin
+        std::vector<int> devs;
+        if (const char *e = std::getenv("PARASUITE_GPU_IDS")) { for (const char *p = e; *p;) { devs.push_back(std::atoi(p)); while (*p && *p != ',') ++p; if (*p == ',') ++p; } }
+        else {
+            int want = 1, have = 0;
+            if (const char *e = std::getenv("PARASUITE_GPUS")) want = std::max(1, std::atoi(e));
+            if (hipGetDeviceCount(&have) != hipSuccess || have < 1) return fail("no HIP device available");
+            for (int g = 0; g < std::min(want, have); ++g) devs.push_back(g);
+        }
+        if (devs.empty()) devs.push_back(0);
+        const int G = (int)devs.size();
+
+        struct Piece { int64_t seq = 0; std::unique_ptr<Batch> b; };
+        Chan<Piece> parsed;
+        // the contexts (stream, options) exist before any index is loaded: the parser stage needs the cost model to bin
         // and pack the reads, not the index
-        ps_ctx *x = new_ctx(0);
-        if (error_profile && error_profile[0] ? ps_ctx_set_profile(x, error_profile, indel_profile, mm)
-                                               : ps_ctx_set_stock(x, mm && mm[0] ? mm : "0.04")) { const std::string m = g_err; ps_ctx_close(x); return fail(m); }
-        x->c.host_threads = nthr;
-        std::exception_ptr perr, werr;
-        double t_parse = 0, t_write = 0;
-        // ---- stage 1: parser (starts at once; the file is read whole, then parsed piece by piece)
+        std::vector<ps_ctx *> xs((size_t)G, nullptr);
+        auto close_all = [&]() { for (ps_ctx *c : xs) if (c) ps_ctx_close(c); };
+        for (int g = 0; g < G; ++g) {
+            xs[g] = new_ctx(devs[g]);
+            if (error_profile && error_profile[0] ? ps_ctx_set_profile(xs[g], error_profile, indel_profile, mm)
+                                                   : ps_ctx_set_stock(xs[g], mm && mm[0] ? mm : "0.04")) { const std::string m = g_err; close_all(); return fail(m); }
+            xs[g]->c.host_threads = nthr;
+        }
+        std::mutex mu; std::condition_variable cv;       // guards: failure, the tie-break chain, the finished pieces
+        bool failed = false; std::string msg;
+        int64_t next_select = 0; uint64_t draws = 0;
+        std::map<int64_t, std::unique_ptr<Batch>> done; bool workers_done = false;
+        auto fail_all = [&](const std::string &m) { { std::lock_guard<std::mutex> l(mu); if (!failed) { failed = true; msg = m; } } cv.notify_all(); parsed.abort(); };
+        double t_parse = 0, t_write = 0, t_index = 0; std::vector<double> t_gpu((size_t)G, 0.0);
+        int64_t n_reads = 0, n_pieces = 0;
+        // ---- parser (starts at once; the file is read whole, then parsed piece by piece)
         std::thread parser([&]() {
             try {
+                int64_t seq = 0;
                 load_reads_chunked(fastq, std::max(1, nthr / 2), chunk_bytes, [&](ReadSet &&rs) {
-                    parsed.push(batch_prepare(&x->c, std::move(rs), std::max(1, nthr / 2)));     // bins, order, 2-bit packing: host only
+                    Piece p; p.seq = seq++; p.b = batch_prepare(&xs[0]->c, std::move(rs), std::max(1, nthr / 2));     // host only
+                    parsed.push(std::move(p));
                 });
                 t_parse = since();
-            } catch (...) { perr = std::current_exception(); }
+            } catch (const std::exception &e) { fail_all(e.what()); }
             parsed.close();
         });
-        // ---- stage 3: writer
+        // ---- writer: pieces in input order
         std::thread writer([&]() {
             try {
-                std::unique_ptr<Batch> b; bool first = true;
-                while (mapped.pop(b)) {
+                int64_t want = 0; bool first = true;
+                for (;;) {
+                    std::unique_ptr<Batch> b;
+                    {
+                        std::unique_lock<std::mutex> l(mu);
+                        cv.wait(l, [&] { return failed || done.count(want) || (workers_done && done.empty()); });
+                        if (failed) return;
+                        auto it = done.find(want);
+                        if (it == done.end()) break;                       // all workers finished and nothing is left
+                        b = std::move(it->second); done.erase(it);
+                    }
                     const auto t0 = std::chrono::steady_clock::now();
-                    batch_write_sam(*b, out_sam, first, "@PG\tID:parasuite-hip\tPN:parasuite-hip\tVN:0.1", nthr, !first);   // the parser is done by now; the GPU stage needs its threads only in bursts
+                    batch_write_sam(*b, out_sam, first, "@PG\tID:parasuite-hip\tPN:parasuite-hip\tVN:0.1", nthr, !first);
                     t_write += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-                    first = false; b.reset();
+                    first = false; ++want;
                 }
-                if (first) {                      // no reads at all: header only
+                if (first) {                      // no reads at all: an empty file
                     FILE *f = std::fopen(out_sam, "wb");
                     if (!f) throw Error(std::string("cannot write ") + out_sam);
                     std::fclose(f);
                 }
-            } catch (...) { werr = std::current_exception(); mapped.abort(); }
+            } catch (const std::exception &e) { fail_all(e.what()); }
         });
-        // ---- stage 2: this thread
-        int rc = 0; std::string msg;
-        double t_index = 0, t_gpu = 0; int64_t n_reads = 0; int n_pieces = 0;
-        try {
-            require_device(x->c.device);
-            if (index_files_exist(ref_fa)) index_load(ref_fa, x->c.ix, x->c.stream);
-            else { index_build(ref_fa, x->c.ix, x->c.stream); index_save(x->c.ix, ref_fa); }
-            t_index = since();
-            uint64_t draws = 0;
-            std::unique_ptr<Batch> b;
-            bool header_only = true;
-            while (parsed.pop(b)) {
-                const auto t0 = std::chrono::steady_clock::now();
-                n_reads += b->rs.n; ++n_pieces;
-                batch_upload(*b);
-                const double w_create = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-                batch_search(*b);
-                const double w_search = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() - w_create;
-                batch_select_hard(*b, draws, &draws);
-                batch_select_easy(*b, nthr);
-                batch_locate(*b);
-                if (verbose) {
-                    const Timing &t = b->tm;
-                    std::fprintf(stderr, "[parasuite-hip]   piece %d: %lld reads; upload %.0f ms, search stage %.0f ms wall (width %.0f backtrack %.0f classify %.0f), select %.0f+%.0f sa2pos %.0f refine %.0f host_post %.0f ms\n",
-                                 n_pieces, (long long)b->rs.n, 1e3 * w_create, 1e3 * w_search, t.ms_width, t.ms_backtrack, t.ms_classify, t.ms_sel_hard, t.ms_sel_easy, t.ms_sa2pos, t.ms_refine, t.ms_host_post);
+        // ---- one worker per device
+        auto worker = [&](int g) {
+            try {
+                Ctx &c = xs[g]->c;
+                require_device(c.device);
+                index_load(ref_fa, c.ix, c.stream);
+                if (g == 0) t_index = since();
+                Piece p;
+                while (parsed.pop(p)) {
+                    { std::lock_guard<std::mutex> l(mu); if (failed) return; n_reads += p.b->rs.n; ++n_pieces; }
+                    const auto t0 = std::chrono::steady_clock::now();
+                    Batch &b = *p.b;
+                    b.ctx = &c;                                        // the piece was packed with the (identical) options of context 0
+                    batch_upload(b);
+                    const double w_up = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                    batch_search(b);
+                    const double w_search = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() - w_up;
+                    {                                                   // the tie-break stream: pieces take their turn in input order
+                        std::unique_lock<std::mutex> l(mu);
+                        cv.wait(l, [&] { return failed || next_select == p.seq; });
+                        if (failed) return;
+                        uint64_t after = 0;
+                        batch_select_hard(b, draws, &after);
+                        draws = after; ++next_select;
+                    }
+                    cv.notify_all();
+                    batch_select_easy(b, nthr);
+                    batch_locate(b);
+                    if (verbose) {
+                        const Timing &t = b.tm;
+                        std::fprintf(stderr, "[parasuite-hip]   piece %lld on device %d: %lld reads; upload %.0f ms, search stage %.0f ms wall (width %.0f backtrack %.0f classify %.0f), select %.0f+%.0f sa2pos %.0f refine %.0f host_post %.0f ms\n",
+                                     (long long)p.seq + 1, c.device, (long long)b.rs.n, 1e3 * w_up, 1e3 * w_search, t.ms_width, t.ms_backtrack, t.ms_classify, t.ms_sel_hard, t.ms_sel_easy, t.ms_sa2pos, t.ms_refine, t.ms_host_post);
+                    }
+                    t_gpu[g] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                    { std::lock_guard<std::mutex> l(mu); done[p.seq] = std::move(p.b); }
+                    cv.notify_all();
                 }
-                t_gpu += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-                header_only = false;
-                mapped.push(std::move(b));
-                if (werr) break;
+            } catch (const std::exception &e) { fail_all(e.what()); }
+        };
+        bool have_index = true;
+        try {
+            if (!index_files_exist(ref_fa)) {         // the Java probes <ref>.bwt and indexes first; be lenient if it did not
+                require_device(xs[0]->c.device);
+                Index tmp; index_build(ref_fa, tmp, xs[0]->c.stream); index_save(tmp, ref_fa);
             }
-            (void)header_only;
-        } catch (const std::exception &e) { rc = 1; msg = e.what(); }
+        } catch (const std::exception &e) { have_index = false; fail_all(e.what()); }
+        std::vector<std::thread> workers;
+        if (have_index) for (int g = 1; g < G; ++g) workers.emplace_back(worker, g);
+        if (have_index) worker(0);
+        for (auto &t : workers) t.join();
+        { std::lock_guard<std::mutex> l(mu); workers_done = true; }
+        cv.notify_all();
         parsed.abort();                           // a parser still waiting to hand over a piece must not wait forever
-        mapped.close();
         parser.join(); writer.join();
-        if (!rc && perr) { try { std::rethrow_exception(perr); } catch (const std::exception &e) { rc = 1; msg = e.what(); } }
-        if (!rc && werr) { try { std::rethrow_exception(werr); } catch (const std::exception &e) { rc = 1; msg = e.what(); } }
-        if (x) ps_ctx_close(x);
-        if (rc) return fail(msg);
-        if (verbose)
-            std::fprintf(stderr, "[parasuite-hip] ps_map: %lld reads in %d piece(s), %.3f s; index resident after %.3f s, parser done after %.3f s, "
-                                 "GPU stage busy %.3f s, SAM writer busy %.3f s\n", (long long)n_reads, n_pieces, since(), t_index, t_parse, t_gpu, t_write);
+        done.clear();
+        close_all();
+        if (failed) return fail(msg);
+        if (verbose) {
+            double busy = 0; for (double v : t_gpu) busy += v;
+            std::fprintf(stderr, "[parasuite-hip] ps_map: %lld reads in %lld piece(s) on %d device(s), %.3f s; index resident after %.3f s, parser done after %.3f s, "
+                                 "GPU stages busy %.3f s, SAM writer busy %.3f s\n", (long long)n_reads, (long long)n_pieces, G, since(), t_index, t_parse, busy, t_write);
+        }
         return 0;
     PS_CATCH_INT
 }

@@ -254,12 +254,15 @@ def test_ps_map_streams_in_pieces(mid, workdir, monkeypatch):
     if not os.path.exists(fa + ".bwt"):
         capi.ps_index(fa)
     outs = []
-    for tag, mb in (("one", "4096"), ("many", "1")):
+    for tag, mb, ids in (("one", "4096", None), ("many", "1", None), ("two_workers", "1", "0,0")):
         monkeypatch.setenv("PS_CHUNK_MB", mb)
+        if ids:                                   # two device workers (both on GPU 0 here): pieces are searched out of order,
+            monkeypatch.setenv("PARASUITE_GPU_IDS", ids)      # the tie-break chain and the writer restore input order
         out = os.path.join(workdir, "stream_%s.sam" % tag)
         capi.ps_map(8, "-1", ep, ip, fa, fq, out)
         outs.append(open(out, "rb").read())
-    assert outs[0] == outs[1]
+    monkeypatch.delenv("PARASUITE_GPU_IDS")
+    assert outs[0] == outs[1] == outs[2]
     osam = os.path.join(workdir, "stream.orc.sam")
     mid["orc_index"].map_fastq(orc.profile_opt(P, 2.1e-5, 5.9e-4, -1), fq, osam, n_threads=8)
     g, o = sam_records(os.path.join(workdir, "stream_many.sam")), sam_records(osam)
