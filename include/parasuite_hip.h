@@ -34,7 +34,10 @@ int ps_index(const char *ref_fa);
 
 /* `bwa parasuite` (or `bwa aln` when error_profile is NULL) + `bwa samse` fused: FASTQ in, SAM out.
  * threads: host worker threads for parsing/formatting (the reference's -t).  mm: the -X (profile
- * mode) or -n (stock mode) argument as the Java passes it, e.g. "-1", "2", "0.04". */
+ * mode) or -n (stock mode) argument as the Java passes it, e.g. "-1", "2", "0.04".
+ * Devices: the first PARASUITE_GPUS (environment, default 1), each with its own copy of the index; the
+ * input is cut into pieces that a parser thread, the device workers and a SAM writer work on side by
+ * side; the output does not depend on the cut or on the number of devices. */
 int ps_map(int threads, const char *mm, const char *error_profile, const char *indel_profile,
            const char *ref_fa, const char *fastq, const char *out_sam);
 
