@@ -52,6 +52,9 @@ int     ps_ctx_set_stock(ps_ctx *, const char *n_arg);               /* bwa aln 
 int     ps_ctx_set_profile(ps_ctx *, const char *error_profile, const char *indel_profile, const char *x_arg);
 int     ps_ctx_set_profile_matrix(ps_ctx *, const double P[16], double ins_rate, double del_rate, int x);
 int     ps_ctx_set_tiers(ps_ctx *, const uint32_t pool_cap[3], const int32_t aln_cap[3], int bt_blocks);
+/* measurement runs: the search kernel of the following launches counts its Occ lookups, pushes, pops ... (ps_batch_kstats,
+ * which = 1); the default kernel carries no counters and leaves them zero */
+int     ps_ctx_set_stats(ps_ctx *, int on);
 
 typedef struct {                       /* index geometry + build facts */
     uint64_t seq_len, l_pac, primary, L2[5], n_blocks, n_sa, device_bytes;
@@ -94,7 +97,7 @@ int     ps_batch_n_aln(ps_batch *, int32_t *out, int64_t cap);       /* per read
 int64_t ps_batch_alns(ps_batch *, int64_t read, ps_aln *out, int64_t cap);
 int     ps_batch_hits(ps_batch *, ps_hit *out, int64_t cap);
 int     ps_batch_timing(ps_batch *, ps_timing *out);
-int64_t ps_ctx_read_iters(ps_ctx *, uint32_t *out, int64_t cap);   /* profiling aid (env PS_READ_ITERS=1): iterations per read of the last search launch */
+int64_t ps_ctx_read_iters(ps_ctx *, uint32_t *out, int64_t cap);   /* profiling aid (env PS_READ_ITERS=1): per read of the last search launch two words -- iterations, stack slots used; returns the word count */
 int     ps_batch_kstats(ps_batch *, int which /*0 width 1 backtrack 2 sa2pos*/, ps_kstats *out);
 
 /* ---- after the map step --------------------------------------------------------------

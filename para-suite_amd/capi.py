@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libparasuite_hip.so")
+SO_PATH = os.environ.get("PARASUITE_LIB") or os.path.join(_HERE, "libparasuite_hip.so")   # PARASUITE_LIB: a diagnostic build of the same library
 
 
 class IndexInfo(C.Structure):
@@ -39,7 +39,7 @@ HIT_DTYPE = np.dtype([("pos", "<i8"), ("sa", "<u8"), ("type", "<i4"), ("strand",
                       ("c2", "<i4"), ("n_cigar", "<i4"), ("n_multi", "<i4"), ("cigar", "<u4", 16)], align=True)
 
 EXPORTS = ["ps_version", "ps_last_error", "ps_index", "ps_map", "ps_ctx_open", "ps_ctx_build", "ps_ctx_close",
-           "ps_ctx_set_stock", "ps_ctx_set_profile", "ps_ctx_set_profile_matrix", "ps_ctx_set_tiers", "ps_ctx_info",
+           "ps_ctx_set_stock", "ps_ctx_set_profile", "ps_ctx_set_profile_matrix", "ps_ctx_set_tiers", "ps_ctx_set_stats", "ps_ctx_info",
            "ps_ctx_blob", "ps_ctx_meta", "ps_ctx_from_blobs", "ps_ctx_fetch", "ps_ctx_export_blob", "ps_sam_to_bam", "ps_bam_view", "ps_bam_sort", "ps_bam_index", "ps_batch_from_fastq",
            "ps_batch_from_codes", "ps_batch_free", "ps_batch_n", "ps_batch_search", "ps_batch_select_hard",
            "ps_batch_select_easy", "ps_batch_locate", "ps_batch_run", "ps_batch_write_sam", "ps_batch_n_aln",
@@ -69,6 +69,7 @@ def lib():
     L.ps_ctx_set_profile.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p]
     L.ps_ctx_set_profile_matrix.argtypes = [C.c_void_p, P(C.c_double), C.c_double, C.c_double, C.c_int]
     L.ps_ctx_set_tiers.argtypes = [C.c_void_p, P(C.c_uint32), P(C.c_int32), C.c_int]
+    L.ps_ctx_set_stats.argtypes = [C.c_void_p, C.c_int]
     L.ps_ctx_info.argtypes = [C.c_void_p, P(IndexInfo)]
     L.ps_ctx_blob.argtypes = [C.c_void_p, C.c_int, P(C.c_void_p), P(C.c_uint64)]
     L.ps_ctx_meta.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
@@ -160,6 +161,10 @@ class Ctx:
         pc = (C.c_uint32 * 3)(*pool_cap) if pool_cap else None
         ac = (C.c_int32 * 3)(*aln_cap) if aln_cap else None
         _chk(lib().ps_ctx_set_tiers(self.h, pc, ac, bt_blocks))
+
+    def set_stats(self, on=True):
+        """search launches that follow count their Occ lookups / pushes / pops (Batch.kstats(1)); off = the timed kernel"""
+        _chk(lib().ps_ctx_set_stats(self.h, 1 if on else 0))
 
     def info(self):
         i = IndexInfo()

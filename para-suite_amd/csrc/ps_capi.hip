@@ -53,6 +53,7 @@ static ps_ctx *new_ctx(int device)
     if (const char *e = std::getenv("PS_N_BIG")) x->c.n_big = std::atoi(e);
     if (const char *e = std::getenv("PS_HIT_MIN")) x->c.hit_min = std::atoi(e);
     if (std::getenv("PS_READ_ITERS")) x->c.want_read_iters = true;
+    if (std::getenv("PS_KSTATS")) x->c.want_kstats = true;
     if (const char *e = std::getenv("PS_BT_BLOCKS")) x->c.bt_blocks = std::atoi(e);
     if (const char *e = std::getenv("PS_POOL_CAP")) x->c.pool_cap[0] = (uint32_t)std::atoi(e);
     return x;
@@ -109,6 +110,12 @@ int ps_ctx_set_profile(ps_ctx *x, const char *ep, const char *ip, const char *x_
         double P[16], ins, del; std::string err;
         if (!read_profile_files(ep, ip, P, ins, del, err)) throw Error(err);
         return ps_ctx_set_profile_matrix(x, P, ins, del, x_arg ? std::atoi(x_arg) : -1);
+    PS_CATCH_INT
+}
+int ps_ctx_set_stats(ps_ctx *x, int on)
+{
+    PS_TRY
+        x->c.want_kstats = on != 0; return 0;
     PS_CATCH_INT
 }
 int ps_ctx_set_tiers(ps_ctx *x, const uint32_t pool_cap[3], const int32_t aln_cap[3], int bt_blocks)

@@ -53,7 +53,6 @@ PS_HD void load_blk(const OccBlock *blocks, uint32_t b, Blk &o)
     for (int j = 0; j < 16; ++j) o.x[j] = p[j];
 #endif
 }
-
 // occurrences of every symbol among the first r (1..192) symbols of the block, plus the block base.
 // The symbols are stored as two bit planes (lo = x[4..9], hi = x[10..15], 32 symbols per word), so one
 // prefix mask and three popcounts per 32 symbols give all four counts.
@@ -259,10 +258,10 @@ PS_HD int lm_bytes(int len, int seed_len, int n_buckets, bool wide)
 // into a vector load).  Small fields are packed four to a word.
 struct BtHot {
     const OccBlock *blocks; bwtint primary;
-    uint32_t L2lo[4], L2hi;          // C array of the FM index: low words, bit 32 of L2[c] at bit c
+    uint32_t L2lo[4], L2hi;          // C array of the FM index: low words, bit 32 of L2[c] at bit c (bit 4: bit 32 of n, the root's base)
     uint32_t s_pk[5], u_pk[5];       // substitution costs, one word per read symbol (byte c = text symbol)
     uint32_t p0, p1, p2, p3;
-    uint32_t inv_c_min, max_entries, pool_cap, n_reads;
+    uint32_t inv_c_min, max_entries, pool_cap, n_reads, big_cap;
     PS_HD int len() const { return (int)(p0 & 0xffu); }
     PS_HD int seed_len() const { return (int)((p0 >> 8) & 0xffu); }
     PS_HD int indel_end_skip() const { return (int)((p0 >> 16) & 0xffu); }
@@ -294,6 +293,7 @@ inline bool bt_hot_make(const BtArgs &a, BtHot &h)
     const Model &md = a.md;
     h.blocks = a.ix.blocks; h.primary = a.ix.primary; h.L2hi = 0;
     for (int c = 0; c < 4; ++c) { h.L2lo[c] = (uint32_t)a.ix.L2[c]; h.L2hi |= (uint32_t)((a.ix.L2[c] >> 32) & 1ull) << c; }
+    h.L2hi |= (uint32_t)((a.ix.seq_len >> 32) & 1ull) << 4;
     for (int c = 0; c < 5; ++c) { h.s_pk[c] = md.s_mm_pk[c]; h.u_pk[c] = md.u_mm_pk[c]; }
     const int seed_units = md.max_seed_diff * md.u_tight;
     const bool ok = a.len >= 0 && a.len <= 255 && md.seed_len >= 0 && md.seed_len <= 255 && md.indel_end_skip >= 0 && md.indel_end_skip <= 255 &&
@@ -301,13 +301,13 @@ inline bool bt_hot_make(const BtArgs &a, BtHot &h)
                     seed_units >= 0 && seed_units <= 4095 && md.u_tight >= 0 && md.u_tight <= 255 && md.s_stop >= 0 && md.s_stop <= 255 &&
                     md.s_gapo_ins >= 0 && md.s_gapo_ins <= 255 && md.s_gape >= 0 && md.s_gape <= 255 && md.s_gapo_del >= 0 && md.s_gapo_del <= 255 &&
                     md.u_gapo_ins >= 0 && md.u_gapo_ins <= 255 && md.u_gape >= 0 && md.u_gape <= 255 && md.u_gapo_del >= 0 && md.u_gapo_del <= 255 &&
-                    md.n_buckets >= 0 && md.n_buckets <= 255 && md.max_entries >= 0 && md.inv_c_min >= 0;
+                    md.n_buckets >= 0 && md.n_buckets <= 255 && md.max_entries >= 0 && md.inv_c_min >= 0 && md.max_units <= 255 && a.ix.L2[0] == 0;
     h.p0 = (uint32_t)a.len | ((uint32_t)md.seed_len << 8) | ((uint32_t)md.indel_end_skip << 16) | ((uint32_t)md.max_del_occ << 24);
     h.p1 = (uint32_t)md.max_gapo | ((uint32_t)md.max_gape << 4) | ((md.mode_gape ? 1u : 0u) << 8) | ((md.use_seed ? 1u : 0u) << 9) |
            ((md.profile ? 1u : 0u) << 10) | ((a.n_big ? 1u : 0u) << 11) | ((uint32_t)seed_units << 12) | ((uint32_t)md.u_tight << 24);
     h.p2 = (uint32_t)md.s_gapo_ins | ((uint32_t)md.s_gape << 8) | ((uint32_t)md.s_gapo_del << 16) | ((uint32_t)md.s_stop << 24);
     h.p3 = (uint32_t)md.u_gapo_ins | ((uint32_t)md.u_gape << 8) | ((uint32_t)md.u_gapo_del << 16) | ((uint32_t)md.n_buckets << 24);
-    h.inv_c_min = (uint32_t)md.inv_c_min; h.max_entries = (uint32_t)md.max_entries; h.pool_cap = a.pool_cap; h.n_reads = (uint32_t)a.n_reads;
+    h.inv_c_min = (uint32_t)md.inv_c_min; h.max_entries = (uint32_t)md.max_entries; h.pool_cap = a.pool_cap; h.n_reads = (uint32_t)a.n_reads; h.big_cap = a.big_cap;
     return ok;
 }
 
@@ -508,7 +508,7 @@ PS_HD void bt_finish_read(const BtArgs &a, BtLane &L)
 {
     a.n_aln[L.r] = L.n_aln;
     a.status[L.r] = (uint8_t)L.status;
-    if (a.read_iters) a.read_iters[L.r] = L.st.iters - L.iters0;
+    if (a.read_iters) a.read_iters[2 * (size_t)L.r] = L.st.iters - L.iters0;
     L.mode = M_FETCH;
 }
 

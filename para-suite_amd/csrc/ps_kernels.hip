@@ -8,11 +8,15 @@
 // random HBM load in the same iteration.
 #include <hip/hip_runtime.h>
 #include "ps_core.h"
+#include "ps_narrow.h"
 #include "ps_kernels.h"
 
 namespace ps {
 
 static const int PS_Q_CHUNK = 64;
+#ifndef PS_BT_WAVES
+#define PS_BT_WAVES 4      // resident waves per SIMD the narrow search kernel is compiled for (register budget)
+#endif
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
 {
@@ -92,7 +96,7 @@ __device__ __forceinline__ void pin_hot(BtHot &h, const BtHot &k)
 #pragma unroll
     for (int c = 0; c < 5; ++c) { h.s_pk[c] = pin32(k.s_pk[c]); h.u_pk[c] = pin32(k.u_pk[c]); }
     h.p0 = pin32(k.p0); h.p1 = pin32(k.p1); h.p2 = pin32(k.p2); h.p3 = pin32(k.p3);
-    h.inv_c_min = pin32(k.inv_c_min); h.max_entries = pin32(k.max_entries); h.pool_cap = pin32(k.pool_cap); h.n_reads = pin32(k.n_reads);
+    h.inv_c_min = pin32(k.inv_c_min); h.max_entries = pin32(k.max_entries); h.pool_cap = pin32(k.pool_cap); h.n_reads = pin32(k.n_reads); h.big_cap = pin32(k.big_cap);
 }
 
 struct BtLoop {             // loop-level constants of the kernel (same treatment)
@@ -201,6 +205,119 @@ __global__ void __launch_bounds__(256) k_backtrack(const BtArgs *__restrict__ ap
     flush_stats(a.stats, L.st);
 }
 
+
+// The narrow tiers (16-byte stack entries; ps_narrow.h): same read hand-out and stack growth as above, the lane state
+// packed.  STATS: per-lane counters for the roofline accounting and the per-read profile -- the timed kernel has none.
+template <bool STATS>
+__global__ void __launch_bounds__(256, PS_BT_WAVES) k_backtrack_n(const BtArgs *__restrict__ ap, BtHot hk, int lm_stride)
+{
+    const BtArgs &a = *ap;      // arguments live in device memory: the cold (non-inlined) paths take their address
+    BtHot h; pin_hot(h, hk);
+    uint32_t *const queue = reinterpret_cast<uint32_t *>(pin64(reinterpret_cast<unsigned long long>(a.queue)));
+    const uint32_t n_reads = h.n_reads, fetch_min = pin32((uint32_t)a.fetch_min), hit_min = pin32((uint32_t)a.hit_min);
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int lane_g = blockIdx.x * blockDim.x + threadIdx.x;
+    BtMem m;
+    bt_mem_bind(m, smem + (size_t)threadIdx.x * lm_stride, h.len(), h.seed_len());
+    uint8_t *const pool_private = reinterpret_cast<uint8_t *>(a.pool) + (size_t)lane_g * h.pool_cap * sizeof(Entry16);
+    m.pool = pool_private;
+    m.heads = nullptr;
+    NLane L;
+    nl_init(L);
+    LaneStats st;
+    ls_init(st);
+    NtClock clk;
+    for (int j = 0; j < 4; ++j) clk.tm[j] = 0;
+    clk.t_last = 0;
+#ifdef PS_STAMPS
+    clk.t_last = __builtin_amdgcn_s_memtime();
+#endif
+    const int lane = threadIdx.x & 63;
+    const unsigned long long t_start = STATS ? wall_clock64() : 0ull;
+    uint32_t iters0 = 0;
+    int q_next = 0, q_end = 0;
+    bool exhausted = false;
+    for (;;) {
+        const int mode = nl_mode(L.ctl);
+        const bool want = mode == M_FETCH;
+        if (want && (L.ctl & NL_BIG)) {                        // read done on a large slot: hand the slot back
+            const unsigned int slot = (unsigned int)((reinterpret_cast<uint8_t *>(m.pool) - a.big_pool) / ((size_t)h.big_cap * sizeof(Entry16)));
+            __threadfence();                                   // this lane's stores to the slot land before the next owner's
+            atomicExch(a.big_busy + slot, 0u);
+            m.pool = pool_private;                             // a new read starts on the lane's private stack slice
+            L.ctl &= ~NL_BIG;
+        }
+        const unsigned long long wmask = __ballot(want), lmask = __ballot(mode != M_EXIT), hmask = __ballot(mode == M_HIT);
+        if (lmask == 0) break;
+        const bool stalled = (wmask | hmask) == lmask;          // nobody can advance without being served
+        const bool serve_hit = hmask != 0 && (__popcll(hmask) >= (int)hit_min || stalled);
+        int fetch_r = -1;
+        if (wmask) {
+            const int cnt = __popcll(wmask);
+            if (cnt >= (int)fetch_min || stalled) {
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(wmask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)wmask, 0u));   // idle lanes below this one
+                int served = 0;
+                while (served < cnt) {
+                    if (q_next == q_end) {
+                        if (exhausted) break;
+                        unsigned int base = 0;
+                        if (lane == 0) base = atomicAdd(queue, (unsigned int)PS_Q_CHUNK);
+                        base = (unsigned int)__shfl((int)base, 0, 64);
+                        if (base >= n_reads) { exhausted = true; break; }
+                        q_next = (int)base;
+                        q_end = (int)base + PS_Q_CHUNK < (int)n_reads ? (int)base + PS_Q_CHUNK : (int)n_reads;
+                    }
+                    const int take = q_end - q_next < cnt - served ? q_end - q_next : cnt - served;
+                    if (want && rank >= served && rank < served + take) fetch_r = q_next + (rank - served);
+                    q_next += take; served += take;
+                }
+                if (want && fetch_r < 0 && exhausted) fetch_r = (int)n_reads;   // nothing left: this lane retires
+            }
+        }
+        unsigned long long gmask = __ballot(mode == M_GROW);
+        while (gmask) {                                        // wave-uniform loop over the lanes that need a larger stack
+            const int src = __ffsll((unsigned long long)gmask) - 1;
+            gmask &= gmask - 1;
+            const unsigned int n_big = a.n_big;
+            unsigned int slot = n_big;
+            if (lane == src) {                                 // claim a free slot: rotating start, bounded probing
+                unsigned int at = atomicAdd(a.big_next, 1u) % n_big;
+                for (int tries = 0; tries < 256; ++tries) {
+                    if (atomicCAS(a.big_busy + at, 0u, 1u) == 0u) { slot = at; break; }
+                    at = at + 1u == n_big ? 0u : at + 1u;
+                }
+            }
+            slot = (unsigned int)__shfl((int)slot, src, 64);
+            const unsigned int n_copy = (unsigned int)__shfl((int)nl_bump(L), src, 64);
+            const unsigned long long from = (unsigned long long)__shfl((long long)reinterpret_cast<unsigned long long>(m.pool), src, 64);
+            if (slot < n_big) {
+                const uint4 *sp = reinterpret_cast<const uint4 *>(from);
+                uint4 *dp = reinterpret_cast<uint4 *>(a.big_pool + (size_t)slot * h.big_cap * sizeof(Entry16));
+                for (unsigned int e = (unsigned int)lane; e < n_copy; e += 64u) dp[e] = sp[e];
+                __threadfence();                               // the copies of all lanes are visible before the owner pops from them
+                if (lane == src) { m.pool = dp; L.ctl = nl_set_mode(L.ctl | NL_BIG, M_EXPAND); }
+            } else if (lane == src) L.ctl = nl_set_mode(nl_set_status(L.ctl, RS_OVERFLOW_POOL), M_POP);
+        }
+        nt_iter<STATS>(a, h, L, st, m, fetch_r, serve_hit, &clk);
+        if (STATS && a.read_iters) {                           // per-read profile: iterations and stack slots used
+            const int now = nl_mode(L.ctl);
+            if (mode == M_FETCH && now != M_FETCH && now != M_EXIT) iters0 = st.iters - 1u;
+            if (mode != M_FETCH && mode != M_EXIT && now == M_FETCH) { a.read_iters[2 * (size_t)L.r] = st.iters - iters0; a.read_iters[2 * (size_t)L.r + 1] = nl_bump(L); }
+        }
+    }
+    if (STATS) {
+        // how long this wave was busy (160 ns units, summed over waves in the otherwise unused lf field): the mean wave
+        // time against the kernel time is the share of the launch spent waiting for the last long reads
+        if (lane == 0) st.lf = (uint32_t)((wall_clock64() - t_start) >> 4);
+#ifdef PS_STAMPS
+        // diagnostic build: the four section times of this wave (64-cycle units) replace nodes / pushes / pops / exact
+        st.nodes = lane == 0 ? (uint32_t)(clk.tm[0] >> 6) : 0; st.pushes = lane == 0 ? (uint32_t)(clk.tm[1] >> 6) : 0;
+        st.pops = lane == 0 ? (uint32_t)(clk.tm[2] >> 6) : 0; st.exact = lane == 0 ? (uint32_t)(clk.tm[3] >> 6) : 0;
+#endif
+        flush_stats(a.stats, st);
+    }
+}
+
 // ---- SA row -> text position ----------------------------------------------
 __global__ void __launch_bounds__(256) k_sa2pos(IndexView ix, const bwtint *rows, bwtint *out, int n, KStats *stats)
 {
@@ -255,19 +372,19 @@ void launch_width(const WidthArgs &a, hipStream_t s)
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_width, dim3(blocks), dim3(256), 0, s, a);
 }
-bool launch_backtrack(const BtArgs &a, const BtArgs *d_args, int n_blocks, int lm_stride, hipStream_t s)
+bool launch_backtrack(const BtArgs &a, const BtArgs *d_args, int n_blocks, int lm_stride, hipStream_t s, bool stats, int variant)
 {
     BtHot h;
     if (!bt_hot_make(a, h)) return false;       // a model field outside its packed range
     (void)hipMemcpyAsync(const_cast<BtArgs *>(d_args), &a, sizeof(BtArgs), hipMemcpyHostToDevice, s);
     const size_t lds = (size_t)256 * lm_stride;
-    if (a.wide) {
-        if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_backtrack<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_backtrack<true>, dim3(n_blocks), dim3(256), lds, s, d_args, h, lm_stride);
-    } else {
-        if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_backtrack<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_backtrack<false>, dim3(n_blocks), dim3(256), lds, s, d_args, h, lm_stride);
-    }
+    const void *fn = a.wide ? reinterpret_cast<const void *>(k_backtrack<true>) : variant == 0 ? reinterpret_cast<const void *>(k_backtrack<false>)
+                   : stats ? reinterpret_cast<const void *>(k_backtrack_n<true>) : reinterpret_cast<const void *>(k_backtrack_n<false>);
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (a.wide) hipLaunchKernelGGL(k_backtrack<true>, dim3(n_blocks), dim3(256), lds, s, d_args, h, lm_stride);
+    else if (variant == 0) hipLaunchKernelGGL(k_backtrack<false>, dim3(n_blocks), dim3(256), lds, s, d_args, h, lm_stride);   // round-1 narrow kernel (A/B only)
+    else if (stats) hipLaunchKernelGGL(k_backtrack_n<true>, dim3(n_blocks), dim3(256), lds, s, d_args, h, lm_stride);
+    else hipLaunchKernelGGL(k_backtrack_n<false>, dim3(n_blocks), dim3(256), lds, s, d_args, h, lm_stride);
     return true;
 }
 void launch_sa2pos(const IndexView &ix, const bwtint *rows, bwtint *out, int n, KStats *stats, hipStream_t s)

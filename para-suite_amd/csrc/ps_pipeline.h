@@ -77,7 +77,8 @@ struct Ctx {
     int bt_blocks = 0;             // grid of the backtracking kernel (0 = 4 blocks per CU)
     uint32_t pool_cap[3] = {16384, 65535, 2000064};   // stack entries per lane: 16-byte narrow tiers, then the wide tier
     int aln_cap[3] = {8, 256, 65536};
-    bool want_read_iters = false; std::vector<uint32_t> read_iters;   // profiling aid: last launch's per-read iterations
+    bool want_kstats = false;      // search kernel with counters (KStats of the backtracking stage): measurement runs only
+    bool want_read_iters = false; std::vector<uint32_t> read_iters;   // profiling aid: last launch's per-read profile (iterations, stack slots), two words per read
     int n_big = 4096;              // 1 MB stack slots a launch may hand to reads that outgrow their private slice
     int fetch_min = 8, hit_min = 1;    // batching hits costs more in idle lanes than it saves (measured)
     int host_threads = 8;

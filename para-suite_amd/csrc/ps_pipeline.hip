@@ -377,11 +377,13 @@ static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases
     { EvTimer t(s); launch_width(wa, s); PS_HIP(hipGetLastError()); b.tm.ms_width += t.stop(); ++b.tm.n_width_launches; }
     int dev_cus = 256;
     { hipDeviceProp_t p; if (hipGetDeviceProperties(&p, ctx->device) == hipSuccess && p.multiProcessorCount > 0) dev_cus = p.multiProcessorCount; }
-    const bool wide = pool_cap > 65535 || md.n_buckets > 64;  // narrow entries link with 16-bit indices and keep one 64-bit bucket bitmap
+    // narrow entries link with 16-bit indices, keep one 64-bit bucket bitmap and count inserted / deleted bases in 3 bits each
+    // ... and saturate the count of best hits at 255 (it is only ever compared with max_top2)
+    const bool wide = pool_cap > 65535 || md.n_buckets > 64 || md.max_gapo + md.max_gape > 7 || md.max_top2 >= 255;
     const int lm = lm_bytes(len, seed_len, md.n_buckets, wide);
     int per_cu = (int)((size_t)(160 * 1024) / ((size_t)256 * lm));
     if (per_cu < 1) throw Error("read length / score range too large for the per-lane LDS state");
-    if (per_cu > 4) per_cu = 4;
+    { const char *e = std::getenv("PS_MAX_PER_CU"); const int cap = e ? std::atoi(e) : 4; if (per_cu > cap) per_cu = cap; }   // workgroups per CU the kernel's registers allow (ps_kernels.hip: PS_BT_WAVES)
     int blocks = ctx->bt_blocks > 0 ? ctx->bt_blocks : dev_cus * per_cu;
     int need = (n + 255) / 256;
     if (blocks > need) blocks = need;
@@ -409,13 +411,14 @@ static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases
         PS_HIP(hipMemsetAsync(a.big_busy, 0, (size_t)a.n_big * 4, s));
     }
     uint32_t *riters = nullptr;
-    if (ctx->want_read_iters) { riters = wk->ws_get<uint32_t>("riters", n); PS_HIP(hipMemsetAsync(riters, 0, (size_t)n * 4, s)); a.read_iters = riters; }
+    if (ctx->want_read_iters) { riters = wk->ws_get<uint32_t>("riters", (size_t)n * 2); PS_HIP(hipMemsetAsync(riters, 0, (size_t)n * 8, s)); a.read_iters = riters; }
     { EvTimer t(s);
-      if (!launch_backtrack(a, wk->ws_get<BtArgs>("btargs", 1), blocks, lm, s)) throw Error("cost model outside the ranges the search kernel packs (gap/score fields must fit a byte)");
+      const char *ev = std::getenv("PS_BT_VARIANT");
+      if (!launch_backtrack(a, wk->ws_get<BtArgs>("btargs", 1), blocks, lm, s, ctx->want_kstats || ctx->want_read_iters, ev ? std::atoi(ev) : 1)) throw Error("cost model outside the ranges the search kernel packs (gap/score fields must fit a byte)");
       PS_HIP(hipGetLastError());
       const double ms = t.stop(); b.tm.ms_backtrack += ms; ++b.tm.n_backtrack_launches;
       if (std::getenv("PS_VERBOSE")) std::fprintf(stderr, "[parasuite-hip]   backtrack launch: %d reads x %d bp, stack %u%s, %d lanes, %.1f ms\n", n, len, pool_cap, wide ? " (wide)" : "", n_lanes, ms); }
-    if (ctx->want_read_iters) { ctx->read_iters.resize(n); PS_HIP(hipMemcpyAsync(ctx->read_iters.data(), riters, (size_t)n * 4, hipMemcpyDeviceToHost, s)); PS_HIP(hipStreamSynchronize(s)); }
+    if (ctx->want_read_iters) { ctx->read_iters.resize((size_t)n * 2); PS_HIP(hipMemcpyAsync(ctx->read_iters.data(), riters, (size_t)n * 8, hipMemcpyDeviceToHost, s)); PS_HIP(hipStreamSynchronize(s)); }
 }
 
 // ------------------------------------------------------------- host helpers ------

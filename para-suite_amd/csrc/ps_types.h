@@ -106,7 +106,7 @@ struct BtArgs {
     // stay valid), released when the read is done
     uint8_t *big_pool; uint32_t big_cap, n_big; uint32_t *big_busy; uint32_t *big_next;
     uint32_t *queue;                                  // next unassigned read (waves take chunks of it)
-    uint32_t *read_iters;                             // optional: iterations spent per read (profiling aid)
+    uint32_t *read_iters;                             // optional per-read profile, two words per read: iterations spent, stack slots used (narrow tiers' counting kernel)
     int hit_min;                                      // lanes with a pending hit a wave collects before it records them
     int fetch_min;                                    // idle lanes a wave waits for before it loads new reads
     KStats *stats;

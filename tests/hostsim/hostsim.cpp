@@ -5,6 +5,7 @@
 // from a BWT symbol string supplied by the test (the oracle's), which also
 // pins the block layout.
 #include "../../para-suite_amd/csrc/ps_core.h"
+#include "../../para-suite_amd/csrc/ps_narrow.h"
 #include "../../para-suite_amd/csrc/ps_model.h"
 #include <vector>
 #include <cstring>
@@ -110,35 +111,50 @@ int hs_aln(void *p, const Model *md, int n_reads, int len, const uint8_t *codes,
     int lmb = lm_bytes(len, seed_len, md->n_buckets, wide);
     std::vector<uint8_t *> cur_pool(n_lanes, nullptr);
     std::vector<uint8_t> lm((size_t)n_lanes * lmb);
-    std::vector<BtLane> lanes(n_lanes); std::vector<int> next(n_lanes);
-    for (int t = 0; t < n_lanes; ++t) { memset(&lanes[t], 0, sizeof(BtLane)); lanes[t].mode = M_FETCH; next[t] = t; }
+    std::vector<BtLane> lanes(n_lanes); std::vector<NLane> nlanes(n_lanes); std::vector<LaneStats> nst(n_lanes); std::vector<int> next(n_lanes);
+    for (int t = 0; t < n_lanes; ++t) { memset(&lanes[t], 0, sizeof(BtLane)); lanes[t].mode = M_FETCH; nl_init(nlanes[t]); ls_init(nst[t]); next[t] = t; }
     BtHot h;
+    a.big_cap = wide ? 0 : big_cap;
     if (!bt_hot_make(a, h)) return -2;
     bool any = true;
     while (any) {                                        // lock-step over lanes, like a wave
         any = false;
         for (int t = 0; t < n_lanes; ++t) {
-            BtLane &L = lanes[t];
-            if (L.mode == M_EXIT) { BtMem mm{}; bt_iter<false>(a, h, L, mm, -1, true); continue; }   // the kernel calls retired lanes too: must be a no-op
             BtMem m; uint8_t *mine = lm.data() + (size_t)t * lmb;
             bt_mem_bind(m, mine, len, seed_len);
             uint8_t *priv = pool.data() + (size_t)t * pool_cap * (wide ? sizeof(Entry) : sizeof(Entry16));
-            if (L.mode == M_FETCH || !cur_pool[t]) cur_pool[t] = priv;
-            if (L.mode == M_GROW) {                          // what the kernel does wave-cooperatively
-                if (big_slots.size() < a.n_big) {
-                    big_slots.emplace_back((size_t)big_cap * sizeof(Entry16));
-                    memcpy(big_slots.back().data(), cur_pool[t], (size_t)L.bump * sizeof(Entry16));
-                    cur_pool[t] = big_slots.back().data(); L.cap = big_cap; L.mode = M_EXPAND;
-                } else { L.status = RS_OVERFLOW_POOL; L.mode = M_POP; }
+            if (!wide) {                                     // the narrow tiers: packed lane state (ps_narrow.h)
+                NLane &L = nlanes[t];
+                int mode = nl_mode(L.ctl);
+                if (mode == M_EXIT) { m.pool = priv; m.heads = nullptr; nt_iter<true>(a, h, L, nst[t], m, -1, true); continue; }   // the kernel calls retired lanes too: must be a no-op
+                if (mode == M_FETCH) { cur_pool[t] = priv; L.ctl &= ~NL_BIG; }      // read done: a large slot goes back, the next read starts on the private slice
+                if (!cur_pool[t]) cur_pool[t] = priv;
+                if (mode == M_GROW) {                        // what the kernel does wave-cooperatively
+                    if (big_slots.size() < a.n_big) {
+                        big_slots.emplace_back((size_t)big_cap * sizeof(Entry16));
+                        memcpy(big_slots.back().data(), cur_pool[t], (size_t)nl_bump(L) * sizeof(Entry16));
+                        cur_pool[t] = big_slots.back().data(); L.ctl = nl_set_mode(L.ctl | NL_BIG, M_EXPAND);
+                    } else L.ctl = nl_set_mode(nl_set_status(L.ctl, RS_OVERFLOW_POOL), M_POP);
+                    mode = nl_mode(L.ctl);
+                }
+                m.pool = cur_pool[t]; m.heads = nullptr;
+                int fr = -1;                               // static hand-out here; the kernel deals reads from a queue
+                if (mode == M_FETCH) { fr = next[t] < n_reads ? next[t] : n_reads; next[t] += n_lanes; }
+                nt_iter<true>(a, h, L, nst[t], m, fr, (t & 1) != 0 || (nst[t].iters & 3) == 0);
+                any = true;
+                continue;
             }
-            m.pool = cur_pool[t];
+            BtLane &L = lanes[t];
+            if (L.mode == M_EXIT) { BtMem mm{}; bt_iter<true>(a, h, L, mm, -1, true); continue; }
+            m.pool = priv;
             m.heads = a.heads + (size_t)t * PS_MAX_BUCKETS;
-            int fr = -1;                                   // static hand-out here; the kernel deals reads from a queue
+            int fr = -1;
             if (L.mode == M_FETCH) { fr = next[t] < n_reads ? next[t] : n_reads; next[t] += n_lanes; }
-            if (wide) bt_iter<true>(a, h, L, m, fr, (t & 1) != 0 || L.mode != M_HIT || (L.st.iters & 3) == 0); else bt_iter<false>(a, h, L, m, fr, (t & 1) != 0 || (L.st.iters & 3) == 0);
+            bt_iter<true>(a, h, L, m, fr, (t & 1) != 0 || L.mode != M_HIT || (L.st.iters & 3) == 0);
             any = true;
         }
     }
+    if (!wide) for (int t = 0; t < n_lanes; ++t) lanes[t].st = nst[t];
     if (ks) {
         memset(ks, 0, sizeof *ks);
         for (int t = 0; t < n_lanes; ++t) {
@@ -177,15 +193,25 @@ int hs_unit_rows33(void)
     const bwtint big[] = {0ull, 1ull, 0xFFFFFFFFull, 0x100000000ull, 0x100000001ull, 0x1ABCDEF12ull, PS_MAX_ROWS};
     for (bwtint k : big) for (bwtint l : big) {
         if (l < k) continue;
-        // narrow stack entry
+        // narrow stack entry (ps_narrow.h): words round-trip through a push and a pop
         std::vector<uint8_t> lmem(4096, 0), pool(64 * sizeof(Entry16), 0);
         BtLane L; memset(&L, 0, sizeof L); L.free_head = PS_NIL; L.cap = 64;
         BtMem m; bt_mem_bind(m, lmem.data(), 50, 32); m.pool = pool.data(); m.heads = nullptr;
-        push16(L, m, true, k, l, e16_a(17, true, 3, ST_D, 2, 5), e16_b(7, 6, 9), 9);
         BtArgs a0; memset(&a0, 0, sizeof a0); a0.md.profile = 1; a0.md.n_buckets = 64; a0.pool_cap = 64;
-        BtHot a; bt_hot_make(a0, a);
-        bt_pop<false>(a, L, m);
-        if (L.k != k || L.l != l || L.i != 17 || L.n_mm != 3 || L.state != ST_D || L.n_gapo != 2 || L.n_gape != 5 || L.n_ins != 7 || L.n_del != 6 || L.score != 9) return 1;
+        a0.ix.L2[1] = 0x90000000ull; a0.ix.L2[2] = 0x120000000ull; a0.ix.L2[3] = 0x1B0000000ull; a0.ix.seq_len = 0x1F0000123ull;
+        BtHot a; if (!bt_hot_make(a0, a)) return 7;
+        {
+            NLane N; nl_init(N);
+            const uint32_t wa = 17u | (17u << 8) | (3u << 16) | (((uint32_t)ST_D | (2u << 2) | (5u << 5)) << 24), wb = 7u | (6u << 3) | (3u << 6) | (9u << 9);
+            nt_push(N, m, (uint32_t)k, (uint32_t)l, wa, wb);
+            N.kr = N.lr = N.wa = N.wb = 0;
+            nt_pop(N, m);
+            if (N.kr != (uint32_t)k || N.lr != (uint32_t)l || N.wa != wa || N.wb != wb || nl_n_stack(N) != 0 || N.bm0 != 0) return 1;
+            if (nw_i(N.wa) != 17 || nw_ldp(N.wa) != 17 || nw_mm(N.wa) != 3 || nw_state(N.wa) != ST_D || nw_gapo(N.wa) != 2 || nw_gape(N.wa) != 5 ||
+                nw_ins(N.wb) != 7 || nw_del(N.wb) != 6 || nw_c(N.wb) != 3 || nw_score(N.wb) != 9) return 2;
+            for (uint32_t c = 0; c < 4; ++c) if (nt_base(a, c) != a0.ix.L2[c]) return 8;
+            if (nt_base(a, NW_ROOT_C) != 0x100000000ull) return 9;      // the root: base + low word of n = n
+        }
         // the wide entry
         const BtHot &aw = a;
         std::vector<uint8_t> wpool(64 * sizeof(Entry), 0); std::vector<uint32_t> heads(PS_MAX_BUCKETS, 0);
