@@ -152,6 +152,43 @@ def gen_reads(torch, dev, contigs, n_reads, L, seed, bound=0.6, indels=True):
     return out.numpy()
 
 
+def write_fastq_fast(path, codes, qual_char=73):
+    """fixed-width records straight from the code matrix (names r00000000 ...): numpy, no per-read Python"""
+    n, L = codes.shape
+    lut = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    rec = np.empty((n, 1 + 9 + 1 + L + 3 + L + 1), dtype=np.uint8)
+    idx = np.arange(n, dtype=np.int64)
+    rec[:, 0] = ord("@"); rec[:, 1] = ord("r")
+    rec[:, 2:10] = ((idx[:, None] // (10 ** np.arange(7, -1, -1, dtype=np.int64))[None, :]) % 10 + 48).astype(np.uint8)
+    rec[:, 10] = 10
+    rec[:, 11:11 + L] = lut[codes]
+    rec[:, 11 + L:14 + L] = np.frombuffer(b"\n+\n", dtype=np.uint8)
+    rec[:, 14 + L:14 + 2 * L] = qual_char
+    rec[:, 14 + 2 * L] = 10
+    with open(path, "wb") as f:
+        for a in range(0, n, 1 << 20):
+            f.write(rec[a:a + (1 << 20)].tobytes())
+
+
+def write_java_profile(prefix, P, ins, dele):
+    """the two files ErrorProfiling.java:504-531,545-591 writes (Double.toString values + tab; ins TAB del, no newline)"""
+    def jd(v):
+        v = float(v)
+        if v != v:
+            return "NaN"
+        if v != 0 and (abs(v) < 1e-3 or abs(v) >= 1e7):
+            m, e = ("%.16e" % v).split("e")
+            m = repr(float(m))
+            return "%sE%d" % (m, int(e))
+        return repr(v)
+    with open(prefix + ".errorprofile", "w") as f:
+        for row in P:
+            f.write("".join(jd(v) + "\t" for v in row) + "\n")
+    with open(prefix + ".indelprofile", "w") as f:
+        f.write(jd(ins) + "\t" + jd(dele))
+    return prefix + ".errorprofile", prefix + ".indelprofile"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -165,11 +202,15 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=250000, help="reads of the same workload timed on the CPU oracle (0 = skip)")
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--penalty", choices=["profile", "stock"], default="profile", help="full workload: PAR-CLIP error-profile costs (bwa parasuite) or stock costs (bwa aln -n 0.04)")
+    ap.add_argument("--sub-batches", type=int, default=1, help="2: the batch of a step is mapped as two halves on two lanes (streams) driven by two threads; measured slower than 1 (DESIGN.md section 5)")
+    ap.add_argument("--e2e", type=int, default=1, help="N=1: also time one ps_map call, FASTQ file -> closed SAM file (the reference's own timer scope)")
+    ap.add_argument("--dump-hits", default="", help="directory: every rank saves the per-read hit records of its last step (tests)")
     ap.add_argument("--keep", default="")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: all ranks use GPU 0")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal of the N>1 path (index staged through the host)")
     args = ap.parse_args()
 
+    import threading
     import torch
     import capi
     import sharding
@@ -191,6 +232,8 @@ def main():
         dist.init_process_group(args.backend, **({"device_id": dev} if args.backend == "nccl" else {}))
     threads = args.threads or min(16, max(1, (os.cpu_count() or 8) // max(1, world)))
     log = (lambda *a: print("[bench r%d]" % rank, *a, file=sys.stderr, flush=True))
+    S = 2 if args.sub_batches >= 2 else 1
+    do_e2e = bool(args.e2e) and world == 1
 
     # ---------------- data: genome on every rank (same seed), index built on rank 0 ----------------
     t0 = time.time()
@@ -204,10 +247,10 @@ def main():
         log("genome %.1f Mbp written in %.1fs" % (args.genome_mbp, time.time() - t0))
         t1 = time.time()
         torch.cuda.empty_cache()                    # the suffix sorter wants most of the HBM for a genome of this size
-        ctx = capi.Ctx.build(fa, device=local)
+        ctx = capi.Ctx.build(fa, device=local, save_files=do_e2e)      # the index files are what the e2e leg's ps_map loads
         info = ctx.info()
-        log("index built in %.1fs (library %.0f ms, %d doubling rounds, %.2f GB in HBM)" %
-            (time.time() - t1, info.build_ms, info.sa_rounds, info.device_bytes / 1e9))
+        log("index built in %.1fs (library %.0f ms, %d doubling rounds, %.2f GB in HBM)%s" %
+            (time.time() - t1, info.build_ms, info.sa_rounds, info.device_bytes / 1e9, "; files saved" if do_e2e else ""))
     if world > 1:
         # one-off broadcast of the index blobs over xGMI (RCCL); rank 0 copies device-to-device into the send buffers
         t1 = time.time()
@@ -232,37 +275,84 @@ def main():
         if rank != 0:
             ctx = capi.Ctx.from_blobs(meta, local, [b.data_ptr() for b in blobs], keep=blobs)
         log("index broadcast %.2f GB in %.2fs" % (sum(sizes) / 1e9, time.time() - t1))
+    P = np.array(PROFILE)
+    P[3, 1], P[3, 3] = 0.12, 0.87           # the T->C rate a first mapping pass of PAR-CLIP data yields
     if args.workload == "exact":
         ctx.set_stock("0")
     elif args.penalty == "stock":
         ctx.set_stock("0.04")
     else:
-        P = np.array(PROFILE)
-        P[3, 1], P[3, 3] = 0.12, 0.87       # the T->C rate a first mapping pass of PAR-CLIP data yields
         ctx.set_profile(P, INS_RATE, DEL_RATE, -1)
 
     t1 = time.time()
     codes = gen_reads(torch, dev, contigs, args.reads, args.read_len, 0x5EED0003 + rank, indels=(args.workload == "full"))
     del contigs
     torch.cuda.empty_cache()
-    batch = ctx.batch_from_codes(codes)
-    log("%d reads generated, packed and uploaded in %.1fs" % (args.reads, time.time() - t1))
+    # the batch of a step as S sub-batches (contiguous halves, input order) on S lanes: stream + workspace each
+    ctx.set_lanes(S)
+    cut = [args.reads * j // S for j in range(S + 1)]
+    batches = [ctx.batch_from_codes(codes[cut[j]:cut[j + 1]]) for j in range(S)]
+    log("%d reads generated, packed and uploaded as %d sub-batch(es) in %.1fs" % (args.reads, S, time.time() - t1))
 
     chain = torch.zeros(1, dtype=torch.int64, device=dev if args.backend == "nccl" else "cpu")
-
-    wall = {"search": 0.0, "select_hard": 0.0, "select_easy": 0.0, "locate": 0.0}
+    wall = {"search": 0.0, "select_hard": 0.0, "select_easy": 0.0, "locate": 0.0, "bt_union": 0.0}
 
     def step():
-        t0 = time.perf_counter()
-        batch.search()
-        t1 = time.perf_counter()
-        sharding.chain_stream_position(dist, rank, world, chain, batch.select_hard)   # tie-break stream handed down the ranks
-        t2 = time.perf_counter()
-        batch.select_easy(threads)
-        t3 = time.perf_counter()
-        batch.locate()
-        t4 = time.perf_counter()
-        wall["search"] += t1 - t0; wall["select_hard"] += t2 - t1; wall["select_easy"] += t3 - t2; wall["locate"] += t4 - t3
+        """one pass of the hot path over the whole batch.  Every sub-batch has a thread (ctypes calls release the GIL):
+        search -> [its turn in the tie-break stream: sub-batches, then ranks, in input order] -> bulk selection -> SA walk, MAPQ,
+        DP.  The search kernels of the two lanes overlap on the GPU (the second fills the CUs the first one's last long reads
+        leave idle), and one sub-batch's later stages run under the other's search kernel."""
+        searched = [threading.Event() for _ in range(S)]
+        chosen = [threading.Event() for _ in range(S)]
+        err = []
+        tw = [dict() for _ in range(S)]
+
+        def lane(j):
+            try:
+                t0 = time.perf_counter()
+                batches[j].search()
+                tw[j]["search"] = time.perf_counter() - t0
+                searched[j].set()
+                chosen[j].wait()
+                if err:
+                    return
+                t1 = time.perf_counter()
+                batches[j].select_easy(threads)
+                t2 = time.perf_counter()
+                batches[j].locate()
+                tw[j]["select_easy"] = t2 - t1; tw[j]["locate"] = time.perf_counter() - t2
+            except Exception as e:           # noqa: BLE001 -- reported below, the other lane is released
+                err.append(e)
+                searched[j].set()
+
+        th = [threading.Thread(target=lane, args=(j,)) for j in range(S)]
+        for t in th:
+            t.start()
+
+        def advance(before):                 # the tie-break stream through this rank's sub-batches, in input order
+            for j in range(S):
+                searched[j].wait()
+                if err:
+                    break
+                t0 = time.perf_counter()
+                before = batches[j].select_hard(before)
+                tw[j]["select_hard"] = time.perf_counter() - t0
+                chosen[j].set()
+            return before
+        try:
+            sharding.chain_stream_position(dist, rank, world, chain, advance)
+        finally:
+            for e in chosen:
+                e.set()
+            for t in th:
+                t.join()
+        if err:
+            raise err[0]
+        for k in ("search", "select_hard", "select_easy", "locate"):
+            wall[k] += max(tw[j].get(k, 0.0) for j in range(S))
+        tms = [b.timing() for b in batches]
+        wall["bt_union"] += (max(t["bt_end_ms"] for t in tms) - min(t["bt_begin_ms"] for t in tms)) * 1e-3
+        return tms
 
     def sync():
         torch.cuda.synchronize()
@@ -278,10 +368,9 @@ def main():
     acc = {}
     t_start = time.perf_counter()
     for _ in range(args.steps):
-        step()
-        tm = batch.timing()
-        for k, v in tm.items():
-            acc[k] = acc.get(k, 0) + v
+        for tm in step():
+            for k, v in tm.items():
+                acc[k] = acc.get(k, 0) + v
     sync()
     elapsed = time.perf_counter() - t_start
     if world > 1:
@@ -289,23 +378,42 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    if args.dump_hits:
+        os.makedirs(args.dump_hits, exist_ok=True)
+        np.save(os.path.join(args.dump_hits, "hits_rank%d.npy" % rank), np.concatenate([b.hits() for b in batches]))
     if rank == 0:
         K = max(1, args.steps)
-        ks_bt, ks_w, ks_sa = batch.kstats(1), batch.kstats(0), batch.kstats(2)
-        # kstats hold the counters of the LAST step (all launches of that step: first tier + re-runs of overflowed
-        # reads); times are averaged per step over the K timed steps, and per launch for the report
+        # ---- counters: the timed kernel carries none.  One more, untimed pass of the search stage with the counting kernel,
+        # one sub-batch at a time (nothing overlaps: these launch durations are the kernel alone); the counts of a batch are the
+        # same in every pass (the search is deterministic)
+        ctx.set_stats(True)
+        ks_bt, ks_w, solo_ms = {}, {}, 0.0
+        for b in batches:
+            b.search()
+            solo_ms += b.timing()["ms_backtrack"]
+            for dst, which in ((ks_bt, 1), (ks_w, 0)):
+                for k, v in b.kstats(which).items():
+                    dst[k] = dst.get(k, 0) + v
+        ctx.set_stats(False)
+        for b in batches:                   # leave the batches searched with the timed kernel, selected and located (hits below)
+            b.run(threads)
+        ks_sa = {}
+        for b in batches:
+            for k, v in b.kstats(2).items():
+                ks_sa[k] = ks_sa.get(k, 0) + v
         n_bt = max(1, acc["n_backtrack_launches"])
-        ms_bt_step = acc["ms_backtrack"] / K
+        ms_bt_sum_step = acc["ms_backtrack"] / K          # summed over the launches of a step (two lanes overlap in time)
+        ms_bt_union_step = 1e3 * wall["bt_union"] / K       # first launch's start to last launch's end: the time the kernel had the GPU
         ms_w_step = acc["ms_width"] / K
         # algorithmic bytes: 64 B x distinct Occ blocks touched by the search steps
         alg_bt = 64.0 * (2 * ks_bt["occ_pairs"] - ks_bt["occ_same_blk"])
         alg_w = 64.0 * (2 * ks_w["occ_pairs"] - ks_w["occ_same_blk"])
-        dominant_bt = ms_bt_step >= ms_w_step
+        dominant_bt = ms_bt_union_step >= ms_w_step
         launches_per_step = (n_bt if dominant_bt else max(1, acc["n_width_launches"])) / K
-        ach = (alg_bt / (ms_bt_step * 1e-3) if dominant_bt else alg_w / (ms_w_step * 1e-3)) / 1e9
-        hits = batch.hits()
+        ach = (alg_bt / (ms_bt_union_step * 1e-3) if dominant_bt else alg_w / (ms_w_step * 1e-3)) / 1e9
+        hits = np.concatenate([b.hits() for b in batches])
         res = {
-            "metric": "aligned reads/sec (10Mx50bp PAR-CLIP vs hg19-size genome) on MI355X; SAM bit-exact vs CPU oracle",
+            "metric": "aligned reads/sec (10Mx50bp PAR-CLIP vs hg19-size genome) on MI355X; SAM bit-exact vs own CPU restatement (parity unpinned)",
             "value": world * args.reads * args.steps / elapsed,
             "unit": "reads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -317,12 +425,22 @@ def main():
                                    "error-profile seed + banded extension" if args.workload == "full" else "exact-match seed only",
                                    args.genome_mbp),
                        "reads_per_gpu": args.reads, "read_len": args.read_len, "genome_mbp": args.genome_mbp,
-                       "mode": args.workload, "penalty": args.penalty, "parallelism": "reads sharded x%d, index replicated" % world},
-            "roofline": {"bound": "hbm", "kernel": "k_backtrack" if dominant_bt else "k_width",
+                       "mode": args.workload, "penalty": args.penalty, "sub_batches": S,
+                       "parallelism": "reads sharded x%d, index replicated" % world},
+            "value_scope": "search + samse stages on reads already packed in HBM -> per-read alignment records in pinned host memory "
+                           "(FASTQ parsing, upload and SAM text are outside; see value_e2e)",
+            "roofline": {"bound": "hbm", "kernel": "k_backtrack_n" if dominant_bt else "k_width",
                          "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
+                         "algorithmic_bytes_per_step": (alg_bt if dominant_bt else alg_w),
                          "algorithmic_bytes_per_launch": (alg_bt if dominant_bt else alg_w) / launches_per_step,
-                         "avg_launch_ms": (ms_bt_step if dominant_bt else ms_w_step) / launches_per_step,
                          "launches_per_step": launches_per_step,
+                         "kernel_ms_per_step_union": ms_bt_union_step if dominant_bt else ms_w_step,
+                         "kernel_ms_per_step_sum_of_launches": ms_bt_sum_step if dominant_bt else ms_w_step,
+                         "kernel_ms_per_step_launches_alone": solo_ms if dominant_bt else ms_w_step,
+                         "avg_launch_ms": (ms_bt_sum_step if dominant_bt else ms_w_step) / launches_per_step,
+                         "timing": "HIP events on each lane's own stream around every launch of the timed steps; the two lanes' launches overlap, "
+                                   "so achieved = bytes of a step / (first launch's start to last launch's end); counters from one extra "
+                                   "untimed pass of the counting kernel over the same batch",
                          "width_kernel": {"achieved": alg_w / (ms_w_step * 1e-3) / 1e9, "frac": alg_w / (ms_w_step * 1e-3) / 1e9 / 8000.0}},
             "kernels_ms_per_step": {k: acc[k] / K for k in ("ms_width", "ms_backtrack", "ms_select", "ms_sa2pos",
                                                             "ms_refine", "ms_host_post", "ms_classify", "ms_sel_hard", "ms_sel_easy")},
@@ -337,21 +455,21 @@ def main():
             pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             for e in pt["entries"]:
                 if all(res["config"].get(k) == v for k, v in e["match"].items()) and e["kernel"] == res["roofline"]["kernel"]:
-                    res["roofline"]["traffic"] = (e["fetch_kb"] + e["write_kb"]) * 1024.0 / e["launches"]
-                    res["roofline"]["traffic_source"] = e["source"]
+                    res["roofline"]["traffic"] = (e["fetch_kb"] + e["write_kb"]) * 1024.0 / e["launches"] * launches_per_step
+                    res["roofline"]["traffic_source"] = "from committed profile, not this run: " + e["source"]
         except Exception:
             pass
         # ---------------- CPU baseline: the oracle (a port, not the PARA-suite_aligner binary) ----------------
         if world == 1 and args.cpu_sample > 0:
             try:
                 import orc
-                import simulate as S
+                import simulate as S_
                 t2 = time.time()
                 ns = min(args.cpu_sample, args.reads)
                 sim = dict(codes=codes[:ns], lens=np.full(ns, args.read_len, dtype=np.int32),
                            quals=np.full((ns, args.read_len), 73, dtype=np.uint8))
                 fq = os.path.join(tmpdir, "sample.fq")
-                S.write_fastq(fq, sim, names=["r%d" % i for i in range(ns)])
+                S_.write_fastq(fq, sim, names=["r%d" % i for i in range(ns)])
                 info = ctx.info()
                 oix = orc.Index.from_parts(fa, ctx.bwt_syms_chunked(), info.primary, ctx.sa_samples())
                 if args.workload == "exact":
@@ -365,10 +483,17 @@ def main():
                 log("oracle index adopted in %.1fs; timing %d reads on %d threads" % (time.time() - t2, ns, cores))
                 osam = os.path.join(tmpdir, "sample.orc.sam")
                 r = oix.map_fastq(oopt, fq, osam, n_threads=cores)
-                cpu_rate = ns / (r["t_aln"] + r["t_samse"])
+                # two scopes, like for like with the GPU figures: up to the per-read records (value), and file to file (value_e2e)
+                cpu_rate = ns / (r["t_aln"] + r["t_samse_records"])
+                cpu_rate_e2e = ns / (r["t_parse"] + r["t_aln"] + r["t_samse"])
                 res["cpu_baseline"] = {"value": cpu_rate, "unit": "reads/s", "cores": cores, "kind": "port",
-                                       "sample": "first %d reads of the same batch; oracle aln+samse stages incl. SAM formatting; "
-                                                 "CPU restatement, not the PARA-suite_aligner binary" % ns}
+                                       "scope": "aln + samse stages up to the per-read alignment records (no FASTQ parse, no SAM text): the scope of `value`",
+                                       "value_e2e": cpu_rate_e2e,
+                                       "scope_e2e": "FASTQ parse + aln + samse + SAM text written (index already in memory): the scope of `value_e2e` minus the index load",
+                                       "seconds": {k: r[k] for k in ("t_parse", "t_aln", "t_samse_records", "t_sam_text")},
+                                       "sample": "first %d reads of the same batch; CPU restatement (oracle/ps_oracle.c, OpenMP), not the "
+                                                 "PARA-suite_aligner binary; the index it searches is adopted from the product (see tests for the "
+                                                 "independent index checks)" % ns}
                 # parity of the same sample through the product
                 sb = ctx.batch_from_codes(codes[:ns])
                 sb.run(threads)
@@ -384,10 +509,46 @@ def main():
                 g_l, o_l = strip(gsam), strip(osam)
                 # the RNG stream position differs between "first ns reads alone" and the oracle's identical run: both start at 0
                 res["parity_sample"] = {"reads": ns, "identical_sam_lines": int(sum(a == b for a, b in zip(g_l, o_l))),
-                                        "all_identical": g_l == o_l}
+                                        "all_identical": g_l == o_l, "against": "own CPU restatement (parity unpinned)"}
                 sb.free()
             except Exception as e:  # the baseline is a reported extra; never hide the GPU result
                 res["cpu_baseline"] = {"value": None, "unit": "reads/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+        # ---------------- T_e2e: the reference's own timer scope (PARAsuiteMapping.java:57,94-97) ----------------
+        # index load from its files + FASTQ parse + search + samse + SAM text written and closed: ONE ps_map call, the entry point
+        # a JNI / argv binding calls.  The staged objects above are released first (ps_map brings its own context).
+        if do_e2e:
+            try:
+                for b in batches:
+                    b.free()
+                ctx.close()
+                torch.cuda.empty_cache()
+                t2 = time.time()
+                fq_all = os.path.join(tmpdir, "reads.fq")
+                write_fastq_fast(fq_all, codes)
+                if args.workload == "full" and args.penalty == "profile":
+                    ep, ip = write_java_profile(os.path.join(tmpdir, "bench"), P, INS_RATE, DEL_RATE)
+                    mm = "-1"
+                else:
+                    ep, ip, mm = None, None, ("0" if args.workload == "exact" else "0.04")
+                log("FASTQ (%.2f GB) written in %.1fs; ps_map ..." % (os.path.getsize(fq_all) / 1e9, time.time() - t2))
+                out_sam = os.path.join(tmpdir, "reads.sam")
+                times = []
+                for rep in range(2):                     # the first call also pays one-off allocations of a new process context
+                    t3 = time.perf_counter()
+                    capi.ps_map(threads, mm, ep, ip, fa, fq_all, out_sam)
+                    times.append(time.perf_counter() - t3)
+                res["t_e2e_s"] = min(times)
+                res["value_e2e"] = args.reads / min(times)
+                res["e2e"] = {"scope": "one ps_map call: index files -> HBM, FASTQ file parsed, search + samse, SAM text written and closed "
+                                       "(the scope of the reference's own timer, PARAsuiteMapping.java:57,94-97)",
+                              "seconds_per_call": times, "fastq_bytes": os.path.getsize(fq_all), "sam_bytes": os.path.getsize(out_sam),
+                              "host_threads": threads}
+                for pth in (fq_all, out_sam):
+                    os.remove(pth)
+            except Exception as e:  # noqa: BLE001
+                res["t_e2e_s"] = None
+                res["value_e2e"] = None
+                res["e2e"] = {"failed": repr(e)}
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

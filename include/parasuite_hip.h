@@ -55,6 +55,9 @@ int     ps_ctx_set_tiers(ps_ctx *, const uint32_t pool_cap[3], const int32_t aln
 /* measurement runs: the search kernel of the following launches counts its Occ lookups, pushes, pops ... (ps_batch_kstats,
  * which = 1); the default kernel carries no counters and leaves them zero */
 int     ps_ctx_set_stats(ps_ctx *, int on);
+/* lanes of work (stream + workspace) the batches created afterwards take in turn: 1 (default) or 2 -- two batches on two lanes may
+ * be driven from two threads at once, one's selection / SA walk / DP stages then run under the other's search kernel */
+int     ps_ctx_set_lanes(ps_ctx *, int n);
 
 typedef struct {                       /* index geometry + build facts */
     uint64_t seq_len, l_pac, primary, L2[5], n_blocks, n_sa, device_bytes;
@@ -90,6 +93,7 @@ typedef struct {
     int32_t n_width_launches, n_backtrack_launches;
     int64_t n_overflow_tier1, n_overflow_tier2;
     double ms_classify, ms_rows, ms_sel_hard, ms_sel_easy;   /* host sub-stages */
+    double bt_begin_ms, bt_end_ms;   /* the search launches of this batch on the context's clock: two batches on two lanes overlap */
 } ps_timing;
 typedef struct { uint64_t occ_pairs, occ_same_blk, nodes, pushes, pops, lf_steps, iters, exact_steps; } ps_kstats;
 
@@ -99,6 +103,9 @@ int     ps_batch_hits(ps_batch *, ps_hit *out, int64_t cap);
 int     ps_batch_timing(ps_batch *, ps_timing *out);
 int64_t ps_ctx_read_iters(ps_ctx *, uint32_t *out, int64_t cap);   /* profiling aid (env PS_READ_ITERS=1): per read of the last search launch two words -- iterations, stack slots used; returns the word count */
 int     ps_batch_kstats(ps_batch *, int which /*0 width 1 backtrack 2 sa2pos*/, ps_kstats *out);
+/* host-only check of the read parser: whole file on `threads` threads (chunk_bytes 0) or streamed in windows of chunk_bytes as
+ * ps_map does; out = {reads, bases, order-sensitive hash of names / sequences / qualities, pieces} */
+int     ps_parse_check(const char *reads_path, int threads, uint64_t chunk_bytes, uint64_t out[4]);
 
 /* ---- after the map step --------------------------------------------------------------
  * One call for what PARAsuiteMapping.java:102-133 (`samtools view -bS -t ref x.sam -o x.bam`, `samtools view -q <mapq> -b`)

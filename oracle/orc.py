@@ -229,7 +229,10 @@ class Index:
         if n < 0:
             raise RuntimeError("oracle map: " + lib().orc_last_error().decode())
         lib().orc_set_rng_offset(0)
-        return dict(n=n, t_aln=ta.value, t_samse=ts.value, hits=hits, draws_after=lib().orc_get_rng_draws())
+        tt = (C.c_double * 4)()
+        lib().orc_last_times(tt)
+        return dict(n=n, t_aln=ta.value, t_samse=ts.value, t_parse=tt[0], t_samse_records=tt[2], t_sam_text=tt[3],
+                    hits=hits, draws_after=lib().orc_get_rng_draws())
 
 
 def ksw_global(query, target, w):

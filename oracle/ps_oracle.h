@@ -133,7 +133,8 @@ int64_t  orc_map_fastq(const orc_index_t *, const orc_opt_t *, const char *fastq
                        const char *sai_out, orc_hit_t *hits, int64_t hits_cap, int n_threads,
                        double *t_aln_s, double *t_samse_s);
 void     orc_set_rng_offset(uint64_t draws_before);   /* shard of a larger input: draws consumed before it */
-uint64_t orc_get_rng_draws(void);                     /* stream position after the last orc_map_fastq */
+uint64_t orc_get_rng_draws(void);
+void orc_last_times(double out[4]);   /* last orc_map_fastq: FASTQ parse, aln, samse up to the records, SAM text + file (seconds) */                     /* stream position after the last orc_map_fastq */
 const char *orc_last_error(void);
 
 #ifdef __cplusplus

@@ -24,7 +24,8 @@ class Timing(C.Structure):
                 ("ms_select", C.c_double), ("ms_sa2pos", C.c_double), ("ms_refine", C.c_double),
                 ("ms_host_post", C.c_double), ("ms_total", C.c_double), ("n_width_launches", C.c_int32),
                 ("n_backtrack_launches", C.c_int32), ("n_overflow_tier1", C.c_int64), ("n_overflow_tier2", C.c_int64),
-                ("ms_classify", C.c_double), ("ms_rows", C.c_double), ("ms_sel_hard", C.c_double), ("ms_sel_easy", C.c_double)]
+                ("ms_classify", C.c_double), ("ms_rows", C.c_double), ("ms_sel_hard", C.c_double), ("ms_sel_easy", C.c_double),
+                ("bt_begin_ms", C.c_double), ("bt_end_ms", C.c_double)]
 
 
 class KStats(C.Structure):
@@ -39,11 +40,11 @@ HIT_DTYPE = np.dtype([("pos", "<i8"), ("sa", "<u8"), ("type", "<i4"), ("strand",
                       ("c2", "<i4"), ("n_cigar", "<i4"), ("n_multi", "<i4"), ("cigar", "<u4", 16)], align=True)
 
 EXPORTS = ["ps_version", "ps_last_error", "ps_index", "ps_map", "ps_ctx_open", "ps_ctx_build", "ps_ctx_close",
-           "ps_ctx_set_stock", "ps_ctx_set_profile", "ps_ctx_set_profile_matrix", "ps_ctx_set_tiers", "ps_ctx_set_stats", "ps_ctx_info",
+           "ps_ctx_set_stock", "ps_ctx_set_profile", "ps_ctx_set_profile_matrix", "ps_ctx_set_tiers", "ps_ctx_set_stats", "ps_ctx_set_lanes", "ps_ctx_info",
            "ps_ctx_blob", "ps_ctx_meta", "ps_ctx_from_blobs", "ps_ctx_fetch", "ps_ctx_export_blob", "ps_sam_to_bam", "ps_bam_view", "ps_bam_sort", "ps_bam_index", "ps_batch_from_fastq",
            "ps_batch_from_codes", "ps_batch_free", "ps_batch_n", "ps_batch_search", "ps_batch_select_hard",
            "ps_batch_select_easy", "ps_batch_locate", "ps_batch_run", "ps_batch_write_sam", "ps_batch_n_aln",
-           "ps_batch_alns", "ps_batch_hits", "ps_batch_timing", "ps_batch_kstats", "ps_ctx_read_iters"]
+           "ps_batch_alns", "ps_batch_hits", "ps_batch_timing", "ps_batch_kstats", "ps_ctx_read_iters", "ps_parse_check"]
 
 _LIB = None
 
@@ -70,6 +71,7 @@ def lib():
     L.ps_ctx_set_profile_matrix.argtypes = [C.c_void_p, P(C.c_double), C.c_double, C.c_double, C.c_int]
     L.ps_ctx_set_tiers.argtypes = [C.c_void_p, P(C.c_uint32), P(C.c_int32), C.c_int]
     L.ps_ctx_set_stats.argtypes = [C.c_void_p, C.c_int]
+    L.ps_ctx_set_lanes.argtypes = [C.c_void_p, C.c_int]
     L.ps_ctx_info.argtypes = [C.c_void_p, P(IndexInfo)]
     L.ps_ctx_blob.argtypes = [C.c_void_p, C.c_int, P(C.c_void_p), P(C.c_uint64)]
     L.ps_ctx_meta.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
@@ -165,6 +167,10 @@ class Ctx:
     def set_stats(self, on=True):
         """search launches that follow count their Occ lookups / pushes / pops (Batch.kstats(1)); off = the timed kernel"""
         _chk(lib().ps_ctx_set_stats(self.h, 1 if on else 0))
+
+    def set_lanes(self, n):
+        """batches created afterwards take n (1 or 2) lanes of work in turn; two batches on two lanes may run from two threads"""
+        _chk(lib().ps_ctx_set_lanes(self.h, int(n)))
 
     def info(self):
         i = IndexInfo()
@@ -300,6 +306,14 @@ class Batch:
         k = KStats()
         _chk(lib().ps_batch_kstats(self.h, which, C.byref(k)))
         return {f: getattr(k, f) for f, _ in KStats._fields_}
+
+
+def ps_parse_check(path, threads=1, chunk_bytes=0):
+    """host-only: (reads, bases, hash, pieces) of the read parser -- whole file, or streamed in windows as ps_map does"""
+    L = lib(); L.ps_parse_check.argtypes = [C.c_char_p, C.c_int, C.c_uint64, C.POINTER(C.c_uint64)]
+    out = (C.c_uint64 * 4)()
+    _chk(L.ps_parse_check(path.encode(), int(threads), int(chunk_bytes), out))
+    return tuple(int(v) for v in out)
 
 
 def ps_index(ref_fa):

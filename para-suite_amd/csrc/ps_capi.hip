@@ -49,6 +49,7 @@ static ps_ctx *new_ctx(int device)
     ps_ctx *x = new ps_ctx();
     x->c.device = device;
     PS_HIP(hipStreamCreateWithFlags(&x->c.stream, hipStreamNonBlocking));
+    PS_HIP(hipEventCreate(&x->c.ref_event)); PS_HIP(hipEventRecord(x->c.ref_event, x->c.stream)); PS_HIP(hipEventSynchronize(x->c.ref_event));
     if (const char *e = std::getenv("PS_FETCH_MIN")) x->c.fetch_min = std::atoi(e);       // tuning knobs
     if (const char *e = std::getenv("PS_N_BIG")) x->c.n_big = std::atoi(e);
     if (const char *e = std::getenv("PS_HIT_MIN")) x->c.hit_min = std::atoi(e);
@@ -110,6 +111,13 @@ int ps_ctx_set_profile(ps_ctx *x, const char *ep, const char *ip, const char *x_
         double P[16], ins, del; std::string err;
         if (!read_profile_files(ep, ip, P, ins, del, err)) throw Error(err);
         return ps_ctx_set_profile_matrix(x, P, ins, del, x_arg ? std::atoi(x_arg) : -1);
+    PS_CATCH_INT
+}
+int ps_ctx_set_lanes(ps_ctx *x, int n)
+{
+    PS_TRY
+        if (n < 1 || n > (int)Ctx::N_WORK) throw Error("lanes: 1 or 2");
+        x->c.n_work = n; return 0;
     PS_CATCH_INT
 }
 int ps_ctx_set_stats(ps_ctx *x, int on)
@@ -281,6 +289,7 @@ int ps_batch_timing(ps_batch *b, ps_timing *o)
         o->ms_classify = t.ms_classify; o->ms_rows = t.ms_rows; o->ms_sel_hard = t.ms_sel_hard; o->ms_sel_easy = t.ms_sel_easy;
         o->n_width_launches = t.n_width_launches; o->n_backtrack_launches = t.n_backtrack_launches;
         o->n_overflow_tier1 = b->b->n_overflow[1]; o->n_overflow_tier2 = b->b->n_overflow[2];
+        o->bt_begin_ms = t.bt_begin_ms; o->bt_end_ms = t.bt_end_ms;
         return 0;
     PS_CATCH_INT
 }
@@ -293,13 +302,19 @@ int ps_batch_kstats(ps_batch *b, int which, ps_kstats *o)
     PS_CATCH_INT
 }
 
-// The whole `map` step behind one call.  Stages run side by side on pieces of the input (whole records, about
-// PS_CHUNK_MB of FASTQ each, default 400): a parser thread (parse, bin, 2-bit pack), one GPU worker per device
-// (upload, search, samse stage) and a writer thread formatting SAM in input order.  Devices: the first
-// PARASUITE_GPUS devices (default 1), or the list in PARASUITE_GPU_IDS (a device may be named twice: rehearsal on one
-// GPU); every worker holds its own copy of the index.  Pieces go to whichever worker is free; the one sequential
-// thing, the tie-break stream, is handed from piece to piece in input order (only the reads whose draw count is data
-// dependent sit on that chain), so the SAM does not depend on the cut or on the number of devices.
+// The whole `map` step behind one call.  Stages run side by side on pieces of the input (whole records; the file is
+// streamed, a window at a time): a parser thread (parse, bin, 2-bit pack), GPU workers (upload, search, samse stage) and a
+// writer thread formatting SAM in input order.
+// Devices: the first PARASUITE_GPUS devices (default 1), or the list in PARASUITE_GPU_IDS.  Every device holds ONE copy of
+// the index: the first loads the files, the others receive the three blobs from it over xGMI (hipMemcpyPeerAsync).  Every
+// device has PS_WORKERS_PER_GPU workers (default 2; a device named k times in PARASUITE_GPU_IDS gets at least k), each with
+// its own stream and workspace, so that one piece's tie-break selection, SA walk, DP and record download run under the
+// other's search kernel and the waves that kernel retires towards its end are refilled by the next.  The piece size
+// follows from the input: at least two pieces per worker, at most PS_CHUNK_MB (default 400 MB) of text each.
+// Pieces go to whichever worker is free; the one sequential thing, the tie-break stream, is handed from piece to piece in
+// input order (only the reads whose draw count is data dependent sit on that chain), so the SAM does not depend on the cut,
+// on the number of workers or on the number of devices.  A finished piece gives its device memory back at once and at most
+// a few finished pieces wait for the writer: memory does not grow with the input.
 int ps_map(int threads, const char *mm, const char *error_profile, const char *indel_profile,
            const char *ref_fa, const char *fastq, const char *out_sam)
 {
@@ -308,21 +323,47 @@ int ps_map(int threads, const char *mm, const char *error_profile, const char *i
         const auto t_begin = std::chrono::steady_clock::now();
         auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); };
         const int nthr = threads > 0 ? threads : 1;
-        size_t chunk_bytes = (size_t)400 << 20;
-        if (const char *e = std::getenv("PS_CHUNK_MB")) chunk_bytes = (size_t)std::max(1, std::atoi(e)) << 20;
-        std::vector<int> devs;
-        if (const char *e = std::getenv("PARASUITE_GPU_IDS")) { for (const char *p = e; *p;) { devs.push_back(std::atoi(p)); while (*p && *p != ',') ++p; if (*p == ',') ++p; } }
-        else {
-            int want = 1, have = 0;
-            if (const char *e = std::getenv("PARASUITE_GPUS")) want = std::max(1, std::atoi(e));
-            if (hipGetDeviceCount(&have) != hipSuccess || have < 1) return fail("no HIP device available");
-            for (int g = 0; g < std::min(want, have); ++g) devs.push_back(g);
+        // ---- devices and workers
+        std::vector<int> devs, dev_workers;              // distinct devices in the order named; workers on each
+        int per_dev = 2;
+        if (const char *e = std::getenv("PS_WORKERS_PER_GPU")) per_dev = std::max(1, std::min(std::atoi(e), (int)Ctx::N_WORK));
+        {
+            std::vector<int> named;
+            if (const char *e = std::getenv("PARASUITE_GPU_IDS")) { for (const char *p = e; *p;) { named.push_back(std::atoi(p)); while (*p && *p != ',') ++p; if (*p == ',') ++p; } }
+            else {
+                int want = 1, have = 0;
+                if (const char *e = std::getenv("PARASUITE_GPUS")) want = std::max(1, std::atoi(e));
+                if (hipGetDeviceCount(&have) != hipSuccess || have < 1) return fail("no HIP device available");
+                for (int g = 0; g < std::min(want, have); ++g) named.push_back(g);
+            }
+            if (named.empty()) named.push_back(0);
+            for (int d : named) {
+                size_t k = 0;
+                while (k < devs.size() && devs[k] != d) ++k;
+                if (k == devs.size()) { devs.push_back(d); dev_workers.push_back(0); }
+                ++dev_workers[k];
+            }
+            for (int &w : dev_workers) w = std::min((int)Ctx::N_WORK, std::max(w, per_dev));
         }
-        if (devs.empty()) devs.push_back(0);
         const int G = (int)devs.size();
+        int n_workers = 0; for (int w : dev_workers) n_workers += w;
+        // ---- piece size from the input
+        size_t chunk_bytes = (size_t)400 << 20;
+        if (const char *e = std::getenv("PS_CHUNK_MB")) chunk_bytes = (size_t)std::max(1, std::atoi(e)) << 20;   // stated: taken as it is
+        else {
+            FILE *f = std::fopen(fastq, "rb");
+            if (f) {
+                if (fseeko(f, 0, SEEK_END) == 0) {
+                    const off_t sz = ftello(f);
+                    if (sz > 0) chunk_bytes = std::min(chunk_bytes, std::max<size_t>((size_t)16 << 20, ((size_t)sz + 2 * (size_t)n_workers - 1) / (2 * (size_t)n_workers)));
+                }
+                std::fclose(f);
+            }
+        }
 
         struct Piece { int64_t seq = 0; std::unique_ptr<Batch> b; };
         Chan<Piece> parsed;
+        parsed.cap = (size_t)std::max(2, n_workers);
         // the contexts (stream, options) exist before any index is loaded: the parser stage needs the cost model to bin
         // and pack the reads, not the index
         std::vector<ps_ctx *> xs((size_t)G, nullptr);
@@ -332,15 +373,18 @@ int ps_map(int threads, const char *mm, const char *error_profile, const char *i
             if (error_profile && error_profile[0] ? ps_ctx_set_profile(xs[g], error_profile, indel_profile, mm)
                                                    : ps_ctx_set_stock(xs[g], mm && mm[0] ? mm : "0.04")) { const std::string m = g_err; close_all(); return fail(m); }
             xs[g]->c.host_threads = nthr;
+            xs[g]->c.n_work = dev_workers[g];
         }
-        std::mutex mu; std::condition_variable cv;       // guards: failure, the tie-break chain, the finished pieces
+        std::mutex mu; std::condition_variable cv;       // guards: failure, the tie-break chain, the finished pieces, index hand-out
         bool failed = false; std::string msg;
-        int64_t next_select = 0; uint64_t draws = 0;
-        std::map<int64_t, std::unique_ptr<Batch>> done; bool workers_done = false;
+        int64_t next_select = 0, write_next = 0; uint64_t draws = 0;
+        std::map<int64_t, std::unique_ptr<Batch>> done; int workers_left = n_workers;
+        const size_t done_cap = (size_t)n_workers + 2;   // finished pieces that may wait for the writer
+        std::vector<int> index_state((size_t)G, 0);      // 0 not there, 1 resident
         auto fail_all = [&](const std::string &m) { { std::lock_guard<std::mutex> l(mu); if (!failed) { failed = true; msg = m; } } cv.notify_all(); parsed.abort(); };
-        double t_parse = 0, t_write = 0, t_index = 0; std::vector<double> t_gpu((size_t)G, 0.0);
+        double t_parse = 0, t_write = 0, t_index = 0, t_index_all = 0; std::vector<double> t_gpu((size_t)n_workers, 0.0);
         int64_t n_reads = 0, n_pieces = 0;
-        // ---- parser (starts at once; the file is read whole, then parsed piece by piece)
+        // ---- parser (starts at once)
         std::thread parser([&]() {
             try {
                 int64_t seq = 0;
@@ -355,21 +399,23 @@ int ps_map(int threads, const char *mm, const char *error_profile, const char *i
         // ---- writer: pieces in input order
         std::thread writer([&]() {
             try {
-                int64_t want = 0; bool first = true;
+                bool first = true;
                 for (;;) {
                     std::unique_ptr<Batch> b;
                     {
                         std::unique_lock<std::mutex> l(mu);
-                        cv.wait(l, [&] { return failed || done.count(want) || (workers_done && done.empty()); });
+                        cv.wait(l, [&] { return failed || done.count(write_next) || (workers_left == 0 && done.empty()); });
                         if (failed) return;
-                        auto it = done.find(want);
+                        auto it = done.find(write_next);
                         if (it == done.end()) break;                       // all workers finished and nothing is left
                         b = std::move(it->second); done.erase(it);
                     }
                     const auto t0 = std::chrono::steady_clock::now();
                     batch_write_sam(*b, out_sam, first, "@PG\tID:parasuite-hip\tPN:parasuite-hip\tVN:0.1", nthr, !first);
                     t_write += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-                    first = false; ++want;
+                    first = false;
+                    { std::lock_guard<std::mutex> l(mu); ++write_next; }
+                    cv.notify_all();
                 }
                 if (first) {                      // no reads at all: an empty file
                     FILE *f = std::fopen(out_sam, "wb");
@@ -378,19 +424,27 @@ int ps_map(int threads, const char *mm, const char *error_profile, const char *i
                 }
             } catch (const std::exception &e) { fail_all(e.what()); }
         });
-        // ---- one worker per device
-        auto worker = [&](int g) {
+        // ---- the workers
+        auto worker = [&](int g, int j, int slot) {
             try {
                 Ctx &c = xs[g]->c;
                 require_device(c.device);
-                index_load(ref_fa, c.ix, c.stream);
-                if (g == 0) t_index = since();
+                if (j == 0) {                                          // this device's index: from the files, or from the first device
+                    if (g == 0) { index_load(ref_fa, c.ix, c.stream); t_index = since(); }
+                    else {
+                        { std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return failed || index_state[0] == 1; }); if (failed) return; }
+                        index_clone(xs[0]->c.ix, xs[0]->c.device, c.ix, c.device, c.stream);
+                    }
+                    { std::lock_guard<std::mutex> l(mu); index_state[g] = 1; t_index_all = since(); }
+                    cv.notify_all();
+                } else { std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return failed || index_state[g] == 1; }); if (failed) return; }
                 Piece p;
                 while (parsed.pop(p)) {
                     { std::lock_guard<std::mutex> l(mu); if (failed) return; n_reads += p.b->rs.n; ++n_pieces; }
                     const auto t0 = std::chrono::steady_clock::now();
                     Batch &b = *p.b;
                     b.ctx = &c;                                        // the piece was packed with the (identical) options of context 0
+                    b.work_index = j;
                     batch_upload(b);
                     const double w_up = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
                     batch_search(b);
@@ -406,17 +460,25 @@ int ps_map(int threads, const char *mm, const char *error_profile, const char *i
                     cv.notify_all();
                     batch_select_easy(b, nthr);
                     batch_locate(b);
+                    b.release_device();                                // what is left to do (SAM text) reads host memory only
                     if (verbose) {
                         const Timing &t = b.tm;
-                        std::fprintf(stderr, "[parasuite-hip]   piece %lld on device %d: %lld reads; upload %.0f ms, search stage %.0f ms wall (width %.0f backtrack %.0f classify %.0f), select %.0f+%.0f sa2pos %.0f refine %.0f host_post %.0f ms\n",
-                                     (long long)p.seq + 1, c.device, (long long)b.rs.n, 1e3 * w_up, 1e3 * w_search, t.ms_width, t.ms_backtrack, t.ms_classify, t.ms_sel_hard, t.ms_sel_easy, t.ms_sa2pos, t.ms_refine, t.ms_host_post);
+                        std::fprintf(stderr, "[parasuite-hip]   piece %lld on device %d worker %d: %lld reads; upload %.0f ms, search stage %.0f ms wall (width %.0f backtrack %.0f classify %.0f), select %.0f+%.0f sa2pos %.0f refine %.0f host_post %.0f ms\n",
+                                     (long long)p.seq + 1, c.device, j, (long long)b.rs.n, 1e3 * w_up, 1e3 * w_search, t.ms_width, t.ms_backtrack, t.ms_classify, t.ms_sel_hard, t.ms_sel_easy, t.ms_sa2pos, t.ms_refine, t.ms_host_post);
                     }
-                    t_gpu[g] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-                    { std::lock_guard<std::mutex> l(mu); done[p.seq] = std::move(p.b); }
+                    t_gpu[slot] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                    {
+                        // at most done_cap finished pieces wait for the writer -- but the piece the writer wants next always gets in
+                        std::unique_lock<std::mutex> l(mu);
+                        cv.wait(l, [&] { return failed || done.size() < done_cap || p.seq == write_next; });
+                        if (failed) return;
+                        done[p.seq] = std::move(p.b);
+                    }
                     cv.notify_all();
                 }
             } catch (const std::exception &e) { fail_all(e.what()); }
         };
+        auto worker_exit = [&](int g, int j, int slot) { worker(g, j, slot); { std::lock_guard<std::mutex> l(mu); --workers_left; } cv.notify_all(); };
         bool have_index = true;
         try {
             if (!index_files_exist(ref_fa)) {         // the Java probes <ref>.bwt and indexes first; be lenient if it did not
@@ -425,10 +487,9 @@ int ps_map(int threads, const char *mm, const char *error_profile, const char *i
             }
         } catch (const std::exception &e) { have_index = false; fail_all(e.what()); }
         std::vector<std::thread> workers;
-        if (have_index) for (int g = 1; g < G; ++g) workers.emplace_back(worker, g);
-        if (have_index) worker(0);
+        if (have_index) { int slot = 0; for (int g = 0; g < G; ++g) for (int j = 0; j < dev_workers[g]; ++j) workers.emplace_back(worker_exit, g, j, slot++); }
+        else { std::lock_guard<std::mutex> l(mu); workers_left = 0; }
         for (auto &t : workers) t.join();
-        { std::lock_guard<std::mutex> l(mu); workers_done = true; }
         cv.notify_all();
         parsed.abort();                           // a parser still waiting to hand over a piece must not wait forever
         parser.join(); writer.join();
@@ -437,9 +498,33 @@ int ps_map(int threads, const char *mm, const char *error_profile, const char *i
         if (failed) return fail(msg);
         if (verbose) {
             double busy = 0; for (double v : t_gpu) busy += v;
-            std::fprintf(stderr, "[parasuite-hip] ps_map: %lld reads in %lld piece(s) on %d device(s), %.3f s; index resident after %.3f s, parser done after %.3f s, "
-                                 "GPU stages busy %.3f s, SAM writer busy %.3f s\n", (long long)n_reads, (long long)n_pieces, G, since(), t_index, t_parse, busy, t_write);
+            std::fprintf(stderr, "[parasuite-hip] ps_map: %lld reads in %lld piece(s) of <= %.0f MB, %d device(s) x %d worker(s), %.3f s; index resident after %.3f s (all devices %.3f s), "
+                                 "parser done after %.3f s, GPU stages busy %.3f s (summed over workers), SAM writer busy %.3f s\n", (long long)n_reads, (long long)n_pieces, chunk_bytes / 1048576.0,
+                                 G, dev_workers[0], since(), t_index, t_index_all, t_parse, busy, t_write);
         }
+        return 0;
+    PS_CATCH_INT
+}
+
+// host-only: parse reads the way ps_map does (whole file on `threads` threads, or streamed in windows of chunk_bytes) and
+// summarise what came out -- {reads, bases, order-sensitive hash of names/sequences/qualities, pieces}
+int ps_parse_check(const char *reads_path, int threads, uint64_t chunk_bytes, uint64_t out[4])
+{
+    PS_TRY
+        uint64_t n = 0, bases = 0, h = 1469598103934665603ull, pieces = 0;
+        auto mix = [&](const void *p, size_t len) { const unsigned char *c = (const unsigned char *)p; for (size_t i = 0; i < len; ++i) { h ^= c[i]; h *= 1099511628211ull; } h ^= 0xff; h *= 1099511628211ull; };
+        auto eat = [&](const ReadSet &rs) {
+            ++pieces;
+            for (int64_t i = 0; i < rs.n; ++i) {
+                size_t nl; const char *nm = rs.name(i, nl);
+                mix(nm, nl); mix(rs.seq.data() + rs.off[i], (size_t)rs.len[i]); mix(rs.qual.data() + rs.off[i], (size_t)rs.len[i]);
+                bases += (uint64_t)rs.len[i];
+            }
+            n += (uint64_t)rs.n;
+        };
+        if (chunk_bytes == 0) { ReadSet rs; load_reads(reads_path, rs, threads); eat(rs); }
+        else load_reads_chunked(reads_path, threads, (size_t)chunk_bytes, [&](ReadSet &&rs) { eat(rs); });
+        out[0] = n; out[1] = bases; out[2] = h; out[3] = pieces;
         return 0;
     PS_CATCH_INT
 }

@@ -28,7 +28,8 @@ template <class T> struct DevBuf {
     DevBuf &operator=(DevBuf &&o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; owned = o.owned; o.p = nullptr; o.n = 0; } return *this; }
     ~DevBuf() { release(); }
     void release() { if (p && owned) (void)hipFree(p); p = nullptr; n = 0; owned = true; }
-    void alloc(size_t count) { release(); n = count; if (count) PS_HIP(hipMalloc((void **)&p, count * sizeof(T))); }
+    void alloc(size_t count)                 // n is committed only when the allocation succeeded (a failed hipMalloc leaves an empty buffer)
+    { release(); if (count) { T *q = nullptr; PS_HIP(hipMalloc((void **)&q, count * sizeof(T))); p = q; } n = count; }
     void adopt(T *ptr, size_t count) { release(); p = ptr; n = count; owned = false; }
     void zero(hipStream_t s = 0) { if (n) PS_HIP(hipMemsetAsync(p, 0, n * sizeof(T), s)); }
     void upload(const T *src, size_t count, hipStream_t s = 0) { PS_HIP(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, s)); }
@@ -70,6 +71,8 @@ struct Index {
 void index_build(const char *fa, Index &ix, hipStream_t s);        // GPU suffix sorting (ps_index.hip)
 void index_save(const Index &ix, const std::string &prefix);
 void index_load(const std::string &prefix, Index &ix, hipStream_t s);
+// a second copy of a resident index on another device, over xGMI (hipMemcpyPeerAsync); the caller has made dst_device current
+void index_clone(const Index &src, int src_device, Index &dst, int dst_device, hipStream_t s);
 bool index_files_exist(const std::string &prefix);
 std::string index_meta_serialize(const Index &ix);
 void index_meta_deserialize(const std::string &blob, Index &ix);   // fills ref + view scalars, no device data

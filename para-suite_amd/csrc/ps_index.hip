@@ -601,25 +601,27 @@ template <class T> static void read_dev(const std::string &path, const char *mag
     if (!f) throw Error("cannot open " + path);
     char mg[8]; uint64_t cnt = 0;
     if (std::fread(mg, 1, 8, f) != 8 || std::memcmp(mg, magic8, 8) != 0 || std::fread(&cnt, 8, 1, f) != 1) { std::fclose(f); throw Error("bad header in " + path); }
-    d.alloc(cnt);
+    try { d.alloc(cnt); } catch (...) { std::fclose(f); throw; }
     const size_t total = (size_t)cnt * sizeof(T), PIECE = (size_t)64 << 20;
     if (host_copy) host_copy->resize(total);
-    void *stage[2] = {nullptr, nullptr}; hipEvent_t done[2];
-    for (int k = 0; k < 2; ++k) { PS_HIP(hipHostMalloc(&stage[k], PIECE, hipHostMallocDefault)); PS_HIP(hipEventCreateWithFlags(&done[k], hipEventDisableTiming)); }
+    struct Stage {                                   // released on every way out (a PS_HIP below may throw)
+        void *buf[2] = {nullptr, nullptr}; hipEvent_t done[2] = {nullptr, nullptr}; FILE *f;
+        explicit Stage(FILE *f_) : f(f_) {}
+        ~Stage() { for (int j = 0; j < 2; ++j) { if (buf[j]) (void)hipHostFree(buf[j]); if (done[j]) (void)hipEventDestroy(done[j]); } if (f) std::fclose(f); }
+    } st(f);
+    for (int k = 0; k < 2; ++k) { PS_HIP(hipHostMalloc(&st.buf[k], PIECE, hipHostMallocDefault)); PS_HIP(hipEventCreateWithFlags(&st.done[k], hipEventDisableTiming)); }
     bool ok = true; size_t at = 0; int k = 0; bool used[2] = {false, false};
     while (at < total && ok) {
         const size_t m = std::min(PIECE, total - at);
-        if (used[k]) PS_HIP(hipEventSynchronize(done[k]));            // the copy that last used this buffer has finished
-        ok = std::fread(stage[k], 1, m, f) == m;
+        if (used[k]) PS_HIP(hipEventSynchronize(st.done[k]));         // the copy that last used this buffer has finished
+        ok = std::fread(st.buf[k], 1, m, f) == m;
         if (!ok) break;
-        if (host_copy) std::memcpy(host_copy->data() + at, stage[k], m);
-        PS_HIP(hipMemcpyAsync(reinterpret_cast<uint8_t *>(d.p) + at, stage[k], m, hipMemcpyHostToDevice, s));
-        PS_HIP(hipEventRecord(done[k], s)); used[k] = true;
+        if (host_copy) std::memcpy(host_copy->data() + at, st.buf[k], m);
+        PS_HIP(hipMemcpyAsync(reinterpret_cast<uint8_t *>(d.p) + at, st.buf[k], m, hipMemcpyHostToDevice, s));
+        PS_HIP(hipEventRecord(st.done[k], s)); used[k] = true;
         at += m; k ^= 1;
     }
     PS_HIP(hipStreamSynchronize(s));
-    for (int j = 0; j < 2; ++j) { (void)hipHostFree(stage[j]); (void)hipEventDestroy(done[j]); }
-    std::fclose(f);
     if (!ok) throw Error("truncated " + path);
 }
 
@@ -645,6 +647,27 @@ void index_load(const std::string &prefix, Index &ix, hipStream_t s)
     bwtint primary = ix.view.primary; bwtint L2[5]; std::memcpy(L2, ix.view.L2, sizeof L2);
     ix.refresh_view();
     ix.view.primary = primary; std::memcpy(ix.view.L2, L2, sizeof L2);
+}
+
+// The index of one device copied to another: three blobs over xGMI, no file read (ps_map with several devices loads the
+// files once).  Falls back to a copy staged by the runtime when the devices cannot reach each other directly.
+void index_clone(const Index &src, int src_device, Index &dst, int dst_device, hipStream_t s)
+{
+    dst.ref = src.ref; dst.build_ms = src.build_ms; dst.sa_rounds = src.sa_rounds;
+    int can = 0;
+    if (src_device != dst_device && hipDeviceCanAccessPeer(&can, dst_device, src_device) == hipSuccess && can) {
+        const hipError_t e = hipDeviceEnablePeerAccess(src_device, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+    }
+    dst.blocks.alloc(src.blocks.n); dst.sa.alloc(src.sa.n); dst.pac.alloc(src.pac.n);
+    PS_HIP(hipMemcpyPeerAsync(dst.blocks.p, dst_device, src.blocks.p, src_device, src.blocks.n * sizeof(OccBlock), s));
+    PS_HIP(hipMemcpyPeerAsync(dst.sa.p, dst_device, src.sa.p, src_device, src.sa.n * sizeof(uint32_t), s));
+    PS_HIP(hipMemcpyPeerAsync(dst.pac.p, dst_device, src.pac.p, src_device, src.pac.n, s));
+    PS_HIP(hipStreamSynchronize(s));
+    const bwtint primary = src.view.primary; bwtint L2[5]; std::memcpy(L2, src.view.L2, sizeof L2);
+    dst.view = src.view;
+    dst.refresh_view();
+    dst.view.primary = primary; std::memcpy(dst.view.L2, L2, sizeof L2);
 }
 
 }  // namespace ps

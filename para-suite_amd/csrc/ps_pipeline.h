@@ -3,6 +3,7 @@
 #include <functional>
 #include <map>
 #include <memory>
+#include <mutex>
 #include "ps_host.h"
 
 namespace ps {
@@ -39,6 +40,7 @@ struct SubRead { int64_t g = 0, easy_before = 0, hard_before = 0; uint8_t cls = 
 struct Timing {
     double ms_width = 0, ms_backtrack = 0, ms_compact = 0, ms_select = 0, ms_sa2pos = 0, ms_refine = 0, ms_host_post = 0, ms_total = 0, ms_classify = 0, ms_rows = 0, ms_sel_hard = 0, ms_sel_easy = 0;
     int n_width_launches = 0, n_backtrack_launches = 0;
+    double bt_begin_ms = 0, bt_end_ms = 0;   // first search launch's start / last one's end on the context's clock (overlapping batches: the union)
 };
 
 struct PinBuf {                     // page-locked host staging (D2H at PCIe rate instead of pageable copies)
@@ -72,6 +74,7 @@ struct Work {
 struct Ctx {
     int device = 0;
     hipStream_t stream = nullptr;    // index build / load
+    hipEvent_t ref_event = nullptr;  // the context's clock: recorded once at creation
     Index ix;
     Options opt;
     int bt_blocks = 0;             // grid of the backtracking kernel (0 = 4 blocks per CU)
@@ -86,6 +89,8 @@ struct Ctx {
     std::unique_ptr<Work> work[N_WORK];
     int n_work = 1, next_work = 0; // lanes in use (1: every batch shares one workspace and stream); batches take them in turn
     Work *take_work();             // creates the lane's stream on first use
+    Work *work_at(int i);          // lane i (ps_map: one per worker thread of the device); thread safe
+    std::mutex work_mu;
     ~Ctx();
 };
 
@@ -110,6 +115,7 @@ struct Bin {
 struct Batch {
     Ctx *ctx = nullptr;
     Work *wk = nullptr;            // the lane of work this batch runs on
+    int work_index = -1;           // >= 0: the lane to use (ps_map's workers); -1: the context's next one
     ReadSet rs;
     std::vector<Bin> bins;
     std::vector<int32_t> read_bin, read_local;
@@ -129,6 +135,7 @@ struct Batch {
     const AlnRec *alns_of(int64_t g, int &n);      // downloads the hit lists on first use
     void ensure_host_alns();
     void hit_of(int64_t g, Hit &h) const;
+    void release_device();         // after batch_locate: everything batch_write_sam / hit_of read is in host memory
 };
 
 std::unique_ptr<Batch> batch_create(Ctx *ctx, ReadSet &&rs);   // bins by cost class, packs 2-bit, uploads (= prepare + upload)

@@ -35,12 +35,29 @@ void require_device(int device)
     PS_HIP(hipSetDevice(device));
 }
 
-Ctx::~Ctx() { if (stream) (void)hipStreamDestroy(stream); }
-Work *Ctx::take_work()
+Ctx::~Ctx() { if (ref_event) (void)hipEventDestroy(ref_event); if (stream) (void)hipStreamDestroy(stream); }
+Work *Ctx::work_at(int w)
 {
-    const int w = next_work; next_work = (next_work + 1) % std::max(1, std::min(n_work, (int)N_WORK));
+    std::lock_guard<std::mutex> l(work_mu);
+    if (w < 0 || w >= (int)N_WORK) throw Error("internal: work lane out of range");
     if (!work[w]) { work[w].reset(new Work()); PS_HIP(hipStreamCreateWithFlags(&work[w]->stream, hipStreamNonBlocking)); }
     return work[w].get();
+}
+Work *Ctx::take_work()
+{
+    int w;
+    { std::lock_guard<std::mutex> l(work_mu); w = next_work; next_work = (next_work + 1) % std::max(1, std::min(n_work, (int)N_WORK)); }
+    return work_at(w);
+}
+void Batch::release_device()
+{
+    for (Bin &bin : bins) {
+        bin.bases.release(); bin.nmask.release(); bin.w.release(); bin.cwb.release(); bin.cswb.release(); bin.status.release();
+        bin.alns.release(); bin.n_aln.release(); bin.d_lens.release(); bin.d_ids.release();
+        bin.d_alns.release(); bin.d_n_aln.release(); bin.d_status.release();
+    }
+    d_class.release(); d_eb.release(); d_hb.release(); d_rows.release(); d_pos.release(); d_sel.release(); d_fin.release(); d_stats.release();
+    searched = false;              // the batch can be written, not searched again
 }
 
 // ------------------------------------------------------------- read input ----
@@ -105,23 +122,77 @@ static void parse_reads_range(const char *buf, size_t i0, size_t i1, ReadSet &rs
     }
 }
 
-// FASTQ / FASTA; read name = header up to the first white space, a trailing /1 or /2 removed.  Four-line FASTQ is
-// cut at record boundaries (a line starting with '@' whose second next line starts with '+') and parsed by `threads`.
-// record starts that split [a, b) of the file image into `parts` pieces (FASTQ only; anything else stays whole)
+// ---- record boundaries ----------------------------------------------------------------------------------------
+// A piece of the input must begin at a record.  A line that starts with '@' need not be a header (a quality string may
+// start with '@'), so a candidate is VERIFIED by walking the record: header, sequence lines up to the '+' line, quality
+// lines holding exactly as many characters as the sequence -- and what follows must be the next header or the end.
+// Returns the index behind the record (the start of the next one); 0 if [i, n) does not hold a whole well-formed record
+// at i.  at_eof: n is the end of the input (the last line may lack its newline).
+static size_t record_end(const char *b, size_t i, size_t n, bool at_eof)
+{
+    if (i >= n) return 0;
+    auto line_end = [&](size_t p) { const char *e = (const char *)std::memchr(b + p, '\n', n - p); return e ? (size_t)(e - b) : n; };
+    auto graph_len = [&](size_t p, size_t e) { while (e > p && !std::isgraph((unsigned char)b[e - 1])) --e; return e - p; };
+    if (b[i] == '>') {                                   // FASTA: up to the next '>' at a line start
+        size_t p = line_end(i);
+        if (p >= n) return at_eof ? n : 0;
+        for (++p; p < n; ) { if (b[p] == '>') return p; const size_t e = line_end(p); if (e >= n) return at_eof ? n : 0; p = e + 1; }
+        return at_eof ? n : 0;
+    }
+    if (b[i] != '@') return 0;
+    size_t p = line_end(i);
+    if (p >= n) return 0;
+    ++p;
+    size_t S = 0, Q = 0;
+    for (;;) {                                           // sequence lines
+        if (p >= n) return 0;
+        if (b[p] == '+') break;
+        const size_t e = line_end(p);
+        if (e >= n) return 0;
+        S += graph_len(p, e); p = e + 1;
+    }
+    if (S == 0) return 0;                                // no boundary is placed on an empty record: a quality line '@..' followed by
+                                                         // one '+..' and one '@..' would verify as one
+    { const size_t e = line_end(p); if (e >= n) return 0; p = e + 1; }       // the '+' line
+    while (Q < S) {                                      // quality lines
+        if (p >= n) return 0;
+        const size_t e = line_end(p);
+        Q += graph_len(p, e);
+        if (e >= n) return (Q == S && at_eof) ? n : 0;
+        p = e + 1;
+    }
+    if (Q != S) return 0;
+    if (p < n && b[p] != '@') return 0;
+    return p;
+}
+// first verified record start at or behind `from` (a line start is looked for first), looking at no more than max_lines
+// lines; n if there is none.  One record can verify by coincidence when the candidate is a quality line (header and
+// sequence of the next record counted as "sequence", lengths happening to add up), so three records in a row must verify
+// -- or the input must end behind fewer (at_eof only: a window of a stream that ends earlier rejects the candidate).
+static size_t find_record_start(const char *b, size_t from, size_t n, bool at_eof, int max_lines, char mark /* '@' FASTQ, '>' FASTA: the input's first byte */)
+{
+    size_t i = from;
+    if (i > 0 && i < n && b[i - 1] != '\n') { const char *e = (const char *)std::memchr(b + i, '\n', n - i); i = e ? (size_t)(e - b) + 1 : n; }
+    for (int t = 0; t < max_lines && i < n; ++t) {
+        if (b[i] == mark) {                              // (a FASTQ quality line may start with '>' as well as with '@')
+            size_t p = i; int good = 0;
+            for (; good < 3 && p < n; ++good) { const size_t e = record_end(b, p, n, at_eof); if (!e) break; p = e; }
+            if (good == 3 || (good > 0 && p >= n && at_eof)) return i;
+        }
+        const char *e = (const char *)std::memchr(b + i, '\n', n - i);
+        i = e ? (size_t)(e - b) + 1 : n;
+    }
+    return n;
+}
+// record starts that split [lo, hi) of the file image into about `parts` pieces; a cut is made only where a record start
+// verifies -- otherwise that piece simply stays larger
 static std::vector<size_t> cut_records(const char *b, size_t lo, size_t hi, int parts)
 {
     std::vector<size_t> cut(1, lo);
-    const size_t n = hi;
-    if (parts > 1 && hi - lo > (size_t)(1 << 20) && b[lo] == '@') {
-        auto next_line = [&](size_t i) { const char *e = (const char *)std::memchr(b + i, '\n', n - i); return e ? (size_t)(e - b) + 1 : n; };
+    if (parts > 1 && hi - lo > (size_t)(1 << 20) && (b[lo] == '@' || b[lo] == '>')) {
         for (int t = 1; t < parts; ++t) {
-            size_t i = next_line(lo + (hi - lo) / (size_t)parts * (size_t)t);
-            for (int tries = 0; tries < 8 && i < n; ++tries) {          // first line here that really starts a record
-                const size_t l1 = next_line(i), l2 = l1 < n ? next_line(l1) : n;
-                if (b[i] == '@' && l2 < n && b[l2] == '+') break;
-                i = l1;
-            }
-            if (i < n && i > cut.back()) cut.push_back(i);
+            const size_t i = find_record_start(b, lo + (hi - lo) / (size_t)parts * (size_t)t, hi, true, 64, b[lo]);
+            if (i < hi && i > cut.back()) cut.push_back(i);
         }
     }
     cut.push_back(hi);
@@ -171,7 +242,9 @@ static void read_file(const char *path, std::vector<char> &buf)
 {
     FILE *f = std::fopen(path, "rb");
     if (!f) throw Error(std::string("cannot open reads ") + path);
-    std::fseek(f, 0, SEEK_END); long sz = std::ftell(f); std::fseek(f, 0, SEEK_SET);
+    if (fseeko(f, 0, SEEK_END) != 0) { std::fclose(f); throw Error(std::string("cannot seek in ") + path); }
+    const off_t sz = ftello(f);
+    if (sz < 0 || fseeko(f, 0, SEEK_SET) != 0) { std::fclose(f); throw Error(std::string("cannot size ") + path); }
     buf.resize((size_t)sz + 1);
     if (sz && std::fread(buf.data(), 1, (size_t)sz, f) != (size_t)sz) { std::fclose(f); throw Error(std::string("short read on ") + path); }
     std::fclose(f);
@@ -185,18 +258,42 @@ void load_reads(const char *path, ReadSet &rs, int threads)
     parse_span(buf.data(), 0, buf.size() - 1, threads, rs);
 }
 
-// the same input in pieces of about chunk_bytes (whole records), in order: sink(piece) may block
+// The same input in pieces of about chunk_bytes (whole records), in order; sink(piece) may block.  The file is STREAMED:
+// one window of chunk_bytes (plus the unfinished record carried over from the window before) is in memory at a time,
+// cut at the last record start that verifies; a window in which none does (records larger than the window) grows.
 void load_reads_chunked(const char *path, int threads, size_t chunk_bytes, const std::function<void(ReadSet &&)> &sink)
 {
-    std::vector<char> buf;
-    read_file(path, buf);
-    const size_t n = buf.size() - 1;
-    const int parts = (int)std::max<size_t>(1, (n + chunk_bytes - 1) / std::max<size_t>(1, chunk_bytes));
-    const std::vector<size_t> cut = cut_records(buf.data(), 0, n, parts);
-    for (size_t c = 0; c + 1 < cut.size(); ++c) {
-        ReadSet rs;
-        parse_span(buf.data(), cut[c], cut[c + 1], threads, rs);
-        sink(std::move(rs));
+    FILE *f = std::fopen(path, "rb");
+    if (!f) throw Error(std::string("cannot open reads ") + path);
+    struct Closer { FILE *f; ~Closer() { std::fclose(f); } } closer{f};
+    if (chunk_bytes < 4096) chunk_bytes = 4096;
+    std::vector<char> buf; size_t have = 0; bool eof = false; char mark = 0;
+    while (!eof || have) {
+        size_t want = chunk_bytes > have ? chunk_bytes : have + chunk_bytes;      // grow when the carry-over alone fills a window
+        buf.resize(want + 1);
+        while (!eof && have < want) {
+            const size_t got = std::fread(buf.data() + have, 1, want - have, f);
+            if (got == 0) { if (std::ferror(f)) throw Error(std::string("read error on ") + path); eof = true; }
+            have += got;
+        }
+        if (!mark && have) mark = buf[0];
+        size_t cut = have;
+        if (!eof) {
+            // the last record start that verifies: walk records from a start found in the window's last 256 KB
+            const size_t from = have > ((size_t)256 << 10) ? have - ((size_t)256 << 10) : 0;
+            size_t i = find_record_start(buf.data(), from, have, false, 4096, mark), last = 0;
+            while (i < have) { last = i; const size_t e = record_end(buf.data(), i, have, false); if (!e || e >= have) break; i = e; }
+            if (last == 0) continue;                                               // nothing to cut at: the window grows
+            cut = last;
+        }
+        if (cut) {
+            ReadSet rs;
+            parse_span(buf.data(), 0, cut, threads, rs);
+            if (rs.n) sink(std::move(rs));
+        }
+        std::memmove(buf.data(), buf.data() + cut, have - cut);
+        have -= cut;
+        if (eof && cut == 0) break;
     }
 }
 
@@ -302,7 +399,8 @@ std::unique_ptr<Batch> batch_prepare(Ctx *ctx, ReadSet &&rs_in, int threads)
 void batch_upload(Batch &bb)
 {
     Batch *b = &bb; Ctx *ctx = b->ctx;
-    b->wk = ctx->take_work();
+    require_device(ctx->device);
+    b->wk = b->work_index >= 0 ? ctx->work_at(b->work_index) : ctx->take_work();
     Work *wk = b->wk;
     for (Bin &bin : b->bins) {
         const size_t n = bin.ids.size();
@@ -339,6 +437,8 @@ struct EvTimer {
     hipEvent_t a, b; hipStream_t s;
     explicit EvTimer(hipStream_t st) : s(st) { PS_HIP(hipEventCreate(&a)); PS_HIP(hipEventCreate(&b)); PS_HIP(hipEventRecord(a, s)); }
     double stop() { PS_HIP(hipEventRecord(b, s)); PS_HIP(hipEventSynchronize(b)); float ms = 0; PS_HIP(hipEventElapsedTime(&ms, a, b)); return ms; }
+    // begin / end on the context's clock (ms since its reference event): launches of two streams that overlap in time
+    void span(hipEvent_t ref, double &t_begin, double &t_end) { float x = 0, y = 0; if (ref && hipEventElapsedTime(&x, ref, a) == hipSuccess && hipEventElapsedTime(&y, ref, b) == hipSuccess) { t_begin = x; t_end = y; } }
     ~EvTimer() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
 };
 
@@ -417,6 +517,7 @@ static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases
       if (!launch_backtrack(a, wk->ws_get<BtArgs>("btargs", 1), blocks, lm, s, ctx->want_kstats || ctx->want_read_iters, ev ? std::atoi(ev) : 1)) throw Error("cost model outside the ranges the search kernel packs (gap/score fields must fit a byte)");
       PS_HIP(hipGetLastError());
       const double ms = t.stop(); b.tm.ms_backtrack += ms; ++b.tm.n_backtrack_launches;
+      { double t0_ = 0, t1_ = 0; t.span(ctx->ref_event, t0_, t1_); if (b.tm.n_backtrack_launches == 1) b.tm.bt_begin_ms = t0_; b.tm.bt_end_ms = t1_; }
       if (std::getenv("PS_VERBOSE")) std::fprintf(stderr, "[parasuite-hip]   backtrack launch: %d reads x %d bp, stack %u%s, %d lanes, %.1f ms\n", n, len, pool_cap, wide ? " (wide)" : "", n_lanes, ms); }
     if (ctx->want_read_iters) { ctx->read_iters.resize((size_t)n * 2); PS_HIP(hipMemcpyAsync(ctx->read_iters.data(), riters, (size_t)n * 8, hipMemcpyDeviceToHost, s)); PS_HIP(hipStreamSynchronize(s)); }
 }
@@ -725,6 +826,7 @@ void batch_search(Batch &b)
 
 void Batch::ensure_host_alns()
 {
+    require_device(ctx->device);
     for (Bin &bin : bins) {
         if (bin.host_alns_valid) continue;
         download_alns(wk, (int)bin.ids.size(), bin.aln_cap, bin.d_alns.p, bin.d_n_aln.p, bin.h_n_aln, bin.h_off, bin.h_alns);
@@ -800,6 +902,7 @@ void batch_select_easy(Batch &b, int threads)
 {
     if (!b.selected_hard) throw Error("select_easy before select_hard");
     Ctx *ctx = b.ctx; Work *wk = b.wk; hipStream_t s = wk->stream;
+    require_device(ctx->device);
     auto t0 = Clock::now();
     const int64_t N = b.rs.n;
     (void)threads;

@@ -13,16 +13,43 @@ pytestmark = pytest.mark.gpu
 
 
 def test_two_ranks_bench_rehearsal(tmp_path):
+    """two bench.py ranks (gloo, both on GPU 0), each mapping its shard as two overlapping sub-batches with the tie-break stream
+    chained through sub-batches and ranks: the per-read records of both ranks, concatenated, equal those of ONE process mapping
+    the same reads as one batch.  (RCCL / xGMI itself cannot run on the one-GPU test box: no N > 1 hardware number exists.)"""
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench as B
+    import capi
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dump = str(tmp_path / "hits")
+    mbp, n_reads = 8, 60000
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29655", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu",
-           "--genome-mbp", "8", "--reads", "60000", "--steps", "1", "--warmup", "1", "--cpu-sample", "0"]
+           "--genome-mbp", str(mbp), "--contigs", "4", "--reads", str(n_reads), "--steps", "1", "--warmup", "1", "--cpu-sample", "0", "--sub-batches", "2", "--dump-hits", dump]
     r = subprocess.run(cmd, env=env, timeout=900, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.split("\n") if l.startswith("{")][-1]
     d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["config"]["sub_batches"] == 2
     assert d["mapped_frac"] > 0.8
+    got = np.concatenate([np.load(os.path.join(dump, "hits_rank%d.npy" % k)) for k in range(2)])
+    # the same genome and the same reads (rank r draws its reads from seed 0x5EED0003 + r), one process, one batch
+    dev = torch.device("cuda", 0)
+    contigs = B.gen_genome(torch, dev, mbp * 1_000_000, 4, 0x5EED0002)     # 2 Mbp contigs: with the two-copy segments
+    fa = str(tmp_path / "g.fa")
+    B.write_fasta(fa, contigs)
+    ctx = capi.Ctx.build(fa, device=0)
+    P = np.array(B.PROFILE); P[3, 1], P[3, 3] = 0.12, 0.87
+    ctx.set_profile(P, B.INS_RATE, B.DEL_RATE, -1)
+    codes = np.concatenate([B.gen_reads(torch, dev, contigs, n_reads, 50, 0x5EED0003 + k) for k in range(2)])
+    one = ctx.batch_from_codes(codes)
+    one.run(8)
+    exp = one.hits()
+    assert len(got) == len(exp) == 2 * n_reads
+    for f in ("pos", "sa", "type", "strand", "mapq", "n_mm", "n_gapo", "c1", "c2", "n_cigar", "n_multi"):
+        assert np.array_equal(got[f], exp[f]), f
+    assert (exp["c1"] > 1).sum() > 100       # reads that did need the random tie-break, on both sides of every hand-over
 
 
 def test_sharded_batches_equal_single_batch(multi, workdir):

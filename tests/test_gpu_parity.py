@@ -233,9 +233,11 @@ def test_stack_growth_in_launch(ctx_example, example, workdir):
         ctx_example.set_tiers(pool_cap=[16384, 65535, 2000064], aln_cap=[8, 256, 65536], bt_blocks=0)
 
 
-def test_ps_map_streams_in_pieces(mid, workdir, monkeypatch):
-    """ps_map cuts the input into pieces that a parser thread, the GPU stage and a SAM writer work on side by side; the
-    output must not depend on the cut (the tie-break stream is carried from piece to piece) and equals the oracle's."""
+def test_ps_map_streams_in_pieces(mid, workdir, monkeypatch, capfd):
+    """ps_map streams the input in pieces that a parser thread, the GPU workers (two per device by default, each with its own
+    stream and workspace) and a SAM writer work on side by side; the output must not depend on the cut or on the number of
+    workers (the tie-break stream is carried from piece to piece in input order) and equals the oracle's."""
+    import re
     import capi
     import orc
     import simulate as S
@@ -254,15 +256,27 @@ def test_ps_map_streams_in_pieces(mid, workdir, monkeypatch):
     if not os.path.exists(fa + ".bwt"):
         capi.ps_index(fa)
     outs = []
-    for tag, mb, ids in (("one", "4096", None), ("many", "1", None), ("two_workers", "1", "0,0")):
+    monkeypatch.setenv("PS_VERBOSE", "1")
+    for tag, mb, ids, per in (("one", "4096", None, "1"), ("many", "1", None, "1"), ("two_workers", "1", None, "2"), ("named_twice", "1", "0,0", "1")):
         monkeypatch.setenv("PS_CHUNK_MB", mb)
-        if ids:                                   # two device workers (both on GPU 0 here): pieces are searched out of order,
-            monkeypatch.setenv("PARASUITE_GPU_IDS", ids)      # the tie-break chain and the writer restore input order
+        monkeypatch.setenv("PS_WORKERS_PER_GPU", per)
+        if ids:                                   # a device named twice: two workers on it, one copy of the index
+            monkeypatch.setenv("PARASUITE_GPU_IDS", ids)
         out = os.path.join(workdir, "stream_%s.sam" % tag)
+        capfd.readouterr()
         capi.ps_map(8, "-1", ep, ip, fa, fq, out)
+        err = capfd.readouterr().err
         outs.append(open(out, "rb").read())
+        pieces = re.findall(r"piece (\d+) on device 0 worker (\d+)", err)
+        if tag == "one":
+            assert len(pieces) == 1
+        else:
+            assert len(pieces) >= 4
+        if tag in ("two_workers", "named_twice"):   # pieces are searched out of order by two workers: chain and writer restore it
+            assert {w for _, w in pieces} == {"0", "1"}, err
+            assert "1 device(s) x 2 worker(s)" in err
     monkeypatch.delenv("PARASUITE_GPU_IDS")
-    assert outs[0] == outs[1] == outs[2]
+    assert outs[0] == outs[1] == outs[2] == outs[3]
     osam = os.path.join(workdir, "stream.orc.sam")
     mid["orc_index"].map_fastq(orc.profile_opt(P, 2.1e-5, 5.9e-4, -1), fq, osam, n_threads=8)
     g, o = sam_records(os.path.join(workdir, "stream_many.sam")), sam_records(osam)
