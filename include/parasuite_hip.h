@@ -124,6 +124,17 @@ int     ps_bam_view(const char *in_bam, const char *out_bam, int min_mapq, int t
 int     ps_bam_sort(const char *in_bam, const char *out_bam, int by_name, int threads, ps_bam_stats *stats);
 int     ps_bam_index(const char *bam, int threads);
 
+/* ---- between the two mapping passes -------------------------------------------------------
+ * What `new ErrorProfiling(mapping, reference, maxReadLength).inferErrorProfile(false, false)` writes for the second pass
+ * (src/src/utils/errorprofile/ErrorProfiling.java:100-631, called at src/src/main/Main.java:327-334): counted on the GPU over
+ * the records of the first pass's SAM or BAM file (unmapped, duplicate and position-less records skipped, :155-166; counts
+ * in read orientation, :301-306,376-377), against the reference of an existing index (<ref_fa>.pac/.ann):
+ *   <out_prefix>.errorprofile  4 lines x 4 values, row = reference base, each Double.toString + TAB (NaN if never seen), :504-531
+ *   <out_prefix>.indelprofile  "<ins>\t<del>" without newline, :545-591
+ * out_prefix NULL or "": the mapping file's name, as in the Java.  A read longer than max_read_len is an error (the
+ * Java's arrays would overflow). */
+int     ps_error_profile(const char *mapping_sam_or_bam, const char *ref_fa, int max_read_len, const char *out_prefix);
+
 #ifdef __cplusplus
 }
 #endif

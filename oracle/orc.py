@@ -235,6 +235,28 @@ class Index:
                     hits=hits, draws_after=lib().orc_get_rng_draws())
 
 
+def error_profile(sam_path, fasta_path, max_read_len, out_prefix):
+    """CPU restatement of ErrorProfiling.inferErrorProfile (oracle/orc_profile.c): writes <out_prefix>.errorprofile and
+    .indelprofile, returns the number of records processed"""
+    L = lib()
+    L.orc_error_profile.restype = C.c_long
+    L.orc_error_profile.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_char_p]
+    L.orc_profile_last_error.restype = C.c_char_p
+    n = L.orc_error_profile(sam_path.encode(), fasta_path.encode(), int(max_read_len), out_prefix.encode())
+    if n < 0:
+        raise RuntimeError("oracle error profile: " + L.orc_profile_last_error().decode())
+    return n
+
+
+def java_double(v):
+    """java.lang.Double.toString as the oracle prints it"""
+    L = lib()
+    L.orc_java_double.argtypes = [C.c_double, C.c_char_p]
+    buf = C.create_string_buffer(64)
+    L.orc_java_double(float(v), buf)
+    return buf.value.decode()
+
+
 def ksw_global(query, target, w):
     q = np.ascontiguousarray(query, dtype=np.uint8)
     t = np.ascontiguousarray(target, dtype=np.uint8)

@@ -554,4 +554,36 @@ void bam_index(const char *bam, int threads)
     write_bai(std::string(bam) + ".bai", d, lay);
 }
 
+void load_alignments(const char *path, int threads, AlnTable &out)
+{
+    threads = clamp_threads(threads);
+    unsigned char mg[2] = {0, 0};
+    { FILE *f = std::fopen(path, "rb"); if (!f) throw Err(std::string("cannot open ") + path); const size_t g = std::fread(mg, 1, 2, f); (void)g; std::fclose(f); }
+    Data d;
+    if (mg[0] == 31 && mg[1] == 139) load_bam(path, threads, d, nullptr, nullptr); else load_sam(path, -1, threads, d);
+    out = AlnTable();
+    out.refs = d.refs;
+    const size_t n = d.recs.size();
+    out.ref.resize(n); out.pos.resize(n); out.l_seq.resize(n); out.flag.resize(n); out.cig_off.resize(n); out.n_cig.resize(n); out.seq_off.resize(n);
+    uint64_t bases = 0; uint32_t ops = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const Rec &r = d.recs[i]; const std::string &e = d.enc[r.part];
+        const uint32_t w = rd32(e, r.off + 12), fl = rd32(e, r.off + 16), l_seq = rd32(e, r.off + 20);
+        out.ref[i] = r.ref; out.pos[i] = r.pos; out.flag[i] = fl >> 16; out.l_seq[i] = (int32_t)l_seq;
+        out.n_cig[i] = fl & 0xffff; out.cig_off[i] = ops; out.seq_off[i] = bases;
+        ops += fl & 0xffff; bases += (l_seq + 1) / 2 * 2;          // records start on a byte
+        (void)w;
+    }
+    out.cigar.resize(ops); out.seq.assign((size_t)(bases / 2), 0);
+    par(threads, threads, [&](int t) {
+        for (size_t i = (size_t)t; i < n; i += (size_t)threads) {
+            const Rec &r = d.recs[i]; const std::string &e = d.enc[r.part];
+            const uint32_t l_name = rd32(e, r.off + 12) & 0xff;
+            const size_t cig_at = r.off + 36 + l_name, seq_at = cig_at + 4 * (size_t)out.n_cig[i];
+            for (uint32_t c = 0; c < out.n_cig[i]; ++c) out.cigar[out.cig_off[i] + c] = rd32(e, cig_at + 4 * c);
+            std::memcpy(&out.seq[(size_t)(out.seq_off[i] / 2)], e.data() + seq_at, (size_t)((out.l_seq[i] + 1) / 2));
+        }
+    });
+}
+
 }  // namespace ps

@@ -307,9 +307,10 @@ int ps_batch_kstats(ps_batch *b, int which, ps_kstats *o)
 // writer thread formatting SAM in input order.
 // Devices: the first PARASUITE_GPUS devices (default 1), or the list in PARASUITE_GPU_IDS.  Every device holds ONE copy of
 // the index: the first loads the files, the others receive the three blobs from it over xGMI (hipMemcpyPeerAsync).  Every
-// device has PS_WORKERS_PER_GPU workers (default 2; a device named k times in PARASUITE_GPU_IDS gets at least k), each with
-// its own stream and workspace, so that one piece's tie-break selection, SA walk, DP and record download run under the
-// other's search kernel and the waves that kernel retires towards its end are refilled by the next.  The piece size
+// device has PS_WORKERS_PER_GPU workers (default 1; 2 is allowed, and a device named twice in PARASUITE_GPU_IDS gets two), each
+// with its own stream and workspace.  Two workers on one device were measured SLOWER end to end (4.6 s against 4.2 s for
+// 10 M reads): two persistent search kernels share the CUs evenly instead of one refilling the other's tail, the later
+// stages of one piece starve under the other's kernel, and the second 69 GB workspace costs its allocation.  The piece size
 // follows from the input: at least two pieces per worker, at most PS_CHUNK_MB (default 400 MB) of text each.
 // Pieces go to whichever worker is free; the one sequential thing, the tie-break stream, is handed from piece to piece in
 // input order (only the reads whose draw count is data dependent sit on that chain), so the SAM does not depend on the cut,
@@ -325,7 +326,7 @@ int ps_map(int threads, const char *mm, const char *error_profile, const char *i
         const int nthr = threads > 0 ? threads : 1;
         // ---- devices and workers
         std::vector<int> devs, dev_workers;              // distinct devices in the order named; workers on each
-        int per_dev = 2;
+        int per_dev = 1;
         if (const char *e = std::getenv("PS_WORKERS_PER_GPU")) per_dev = std::max(1, std::min(std::atoi(e), (int)Ctx::N_WORK));
         {
             std::vector<int> named;
@@ -525,6 +526,23 @@ int ps_parse_check(const char *reads_path, int threads, uint64_t chunk_bytes, ui
         if (chunk_bytes == 0) { ReadSet rs; load_reads(reads_path, rs, threads); eat(rs); }
         else load_reads_chunked(reads_path, threads, (size_t)chunk_bytes, [&](ReadSet &&rs) { eat(rs); });
         out[0] = n; out[1] = bases; out[2] = h; out[3] = pieces;
+        return 0;
+    PS_CATCH_INT
+}
+
+// Error-profile estimation from a mapping (the stage between the two passes of a --refine run, Main.java:320-340): what
+// `new ErrorProfiling(mapping, reference, maxReadLength).inferErrorProfile(false, false)` writes for the mapper.
+int ps_error_profile(const char *mapping_sam_or_bam, const char *ref_fa, int max_read_len, const char *out_prefix)
+{
+    PS_TRY
+        ProfileCounts c;
+        int dev = 0;
+        if (const char *e = std::getenv("PARASUITE_GPU_IDS")) dev = std::atoi(e);
+        error_profile_count(mapping_sam_or_bam, ref_fa, max_read_len, dev, 8, c);
+        error_profile_write(c, out_prefix && out_prefix[0] ? out_prefix : mapping_sam_or_bam);
+        if (std::getenv("PS_VERBOSE"))
+            std::fprintf(stderr, "[parasuite-hip] ps_error_profile: %llu records, %llu counted (%llu unmapped, %llu duplicate, %llu without position, %llu with indels, %llu skipped)\n",
+                         c.n_records, c.n_processed, c.n_unmapped, c.n_duplicate, c.n_start_zero, c.n_indel_reads, c.n_skipped);
         return 0;
     PS_CATCH_INT
 }

@@ -74,7 +74,18 @@ void index_load(const std::string &prefix, Index &ix, hipStream_t s);
 // a second copy of a resident index on another device, over xGMI (hipMemcpyPeerAsync); the caller has made dst_device current
 void index_clone(const Index &src, int src_device, Index &dst, int dst_device, hipStream_t s);
 bool index_files_exist(const std::string &prefix);
+void index_load_pac(const std::string &prefix, Index &ix, hipStream_t s);   // .ann + .pac only (error-profile stage)
 std::string index_meta_serialize(const Index &ix);
 void index_meta_deserialize(const std::string &blob, Index &ix);   // fills ref + view scalars, no device data
+
+// ---- error-profile estimation from a mapping (ps_profile.hip; what ErrorProfiling.inferErrorProfile computes) ----
+struct ProfileCounts {                 // raw counts, read orientation; [pos][ref base][read base]
+    int max_len = 0;
+    std::vector<unsigned long long> conv, ins, del;     // conv: max_len*16; ins/del: per alignment column (forward strand), max_len
+    unsigned long long n_records = 0, n_processed = 0, n_unmapped = 0, n_duplicate = 0, n_start_zero = 0, n_indel_reads = 0, n_skipped = 0;
+};
+void error_profile_count(const char *mapping_sam_or_bam, const char *ref_prefix, int max_len, int device, int threads, ProfileCounts &out);
+void error_profile_write(const ProfileCounts &c, const std::string &out_prefix);    // <out_prefix>.errorprofile / .indelprofile
+std::string java_double_to_string(double v);                                        // java.lang.Double.toString
 
 }  // namespace ps

@@ -649,6 +649,17 @@ void index_load(const std::string &prefix, Index &ix, hipStream_t s)
     ix.view.primary = primary; std::memcpy(ix.view.L2, L2, sizeof L2);
 }
 
+// only what the error-profile stage needs of an index: contigs, holes and the packed forward strand on the device
+void index_load_pac(const std::string &prefix, Index &ix, hipStream_t s)
+{
+    std::ifstream a(prefix + ".ann", std::ios::binary);
+    if (!a.good()) throw Error("cannot open " + prefix + ".ann (run ps_index first)");
+    std::stringstream ss; ss << a.rdbuf();
+    index_meta_deserialize(ss.str(), ix);
+    read_dev(prefix + ".pac", "PSPAC001", ix.pac, s, nullptr);
+    ix.view.pac = ix.pac.p; ix.view.l_pac = (bwtint)ix.ref.l_pac;
+}
+
 // The index of one device copied to another: three blobs over xGMI, no file read (ps_map with several devices loads the
 // files once).  Falls back to a copy staged by the runtime when the devices cannot reach each other directly.
 void index_clone(const Index &src, int src_device, Index &dst, int dst_device, hipStream_t s)

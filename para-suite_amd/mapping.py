@@ -105,3 +105,22 @@ class PARAsuiteMapping(Mapping):
                    capi.ps_map, threads, additionalOptions, self.errorProfileFilename, self.indelProfileFilename,
                    reference, input, outputPrefix + ".sam")
         self.seconds = self.calculatePassedTime()
+
+
+class ErrorProfiling:
+    """mirror of utils.errorprofile.ErrorProfiling (ErrorProfiling.java:57-88, 100-631) for what the mapping step uses of it:
+    `new ErrorProfiling(mappingFileName, referenceFileName, maxReadLength).inferErrorProfile(false, false)` leaves
+    <mappingFileName>.errorprofile and <mappingFileName>.indelprofile behind (Main.java:327-334).  The counting runs on the GPU
+    (`ps_error_profile`); the other files the Java writes (.qualities, .indels, .vcf, plots) have no consumer in the path."""
+
+    def __init__(self, mappingFileName, referenceFileName, maxReadLength):
+        self.mappingFileName = mappingFileName
+        self.referenceFileName = referenceFileName
+        self.maxReadLength = maxReadLength
+
+    def inferErrorProfile(self, isInferQualities=False, isShowErrorPlot=False):
+        try:
+            capi.ps_error_profile(self.mappingFileName, self.referenceFileName, self.maxReadLength, None)
+        except capi.PsError as e:
+            raise ExternalCallErrorException("ErrorProfiling %s: %s" % (self.mappingFileName, e))
+        return self.mappingFileName + ".errorprofile", self.mappingFileName + ".indelprofile"
