@@ -113,6 +113,25 @@ int ps_ctx_set_profile(ps_ctx *x, const char *ep, const char *ip, const char *x_
         return ps_ctx_set_profile_matrix(x, P, ins, del, x_arg ? std::atoi(x_arg) : -1);
     PS_CATCH_INT
 }
+// SA[row] for arbitrary rows of the BW matrix (LF walk to a sampled row: the kernel the samse stage uses): index checks
+int ps_ctx_sa_lookup(ps_ctx *x, const uint64_t *rows, int64_t n, uint64_t *out)
+{
+    PS_TRY
+        Ctx &c = x->c;
+        require_device(c.device);
+        if (n < 0 || n > 0x7fffffff) throw Error("sa lookup: bad count");
+        for (int64_t i = 0; i < n; ++i) if (rows[i] < 1 || rows[i] > c.ix.view.seq_len) throw Error("sa lookup: row outside [1, n]");
+        DevBuf<bwtint> d_r, d_p; d_r.alloc((size_t)std::max<int64_t>(1, n)); d_p.alloc((size_t)std::max<int64_t>(1, n));
+        if (n) {
+            d_r.upload((const bwtint *)rows, (size_t)n, c.stream);
+            launch_sa2pos(c.ix.view, d_r.p, d_p.p, (int)n, nullptr, c.stream);
+            PS_HIP(hipGetLastError());
+            d_p.download((bwtint *)out, (size_t)n, c.stream);
+        }
+        PS_HIP(hipStreamSynchronize(c.stream));
+        return 0;
+    PS_CATCH_INT
+}
 int ps_ctx_set_lanes(ps_ctx *x, int n)
 {
     PS_TRY

@@ -2,7 +2,8 @@
 
 A 2.2 Gbp synthetic genome (4.4e9 rows > 2^32) is the smallest input that exercises the high bit everywhere;
 the oracle adopts the product's BWT (it has its own Occ code, search, tie-break, locate and SAM writer) and maps
-the same reads on the CPU.  Besides equality with the oracle the test checks a size-independent property: every
+the same reads on the CPU -- after that BWT, the sampled SA and the C array have been checked against the TEXT: suffix order of
+123,000 adjacent row pairs (random, and across the 2^32 boundary), BWT[r] == T[SA[r]-1], L2 == base counts.  Besides equality with the oracle the test checks a size-independent property: every
 exact read maps back to the position it was cut from, on either strand, including positions above 2^32.
 Takes about two minutes on one MI355X; everything (genome, reads) is generated on the device as in bench.py."""
 import os
@@ -46,6 +47,38 @@ def test_parity_and_round_trip_above_2_pow_32_rows(tmp_path):
     info = ctx.info()
     assert info.seq_len == 2 * mbp * 1_000_000 and info.seq_len > 2 ** 32
     assert sum(int(info.L2[c + 1]) - int(info.L2[c]) for c in range(4)) == info.seq_len
+
+    # ---- the index checked WITHOUT trusting it: properties computed from the text (tests/index_props.py; the same check fails
+    # on a suffix array with unsorted ties, swapped neighbours or a wrong position bit: tests/test_index_props_cpu.py).
+    # The text: the packed forward strand, itself compared with the FASTA codes at every non-N position.
+    sys.path.insert(0, HERE)
+    import index_props as IP
+    pac = ctx.fetch(2)
+    fwd = np.empty(pac.size * 4, dtype=np.uint8)
+    for k in range(4):
+        fwd[k::4] = (pac >> (6 - 2 * k)) & 3
+    fwd = fwd[:info.l_pac]
+    at = 0
+    for _, c in contigs:
+        h = c.cpu().numpy()
+        keep = h < 4
+        assert np.array_equal(fwd[at:at + h.size][keep], h[keep]), "pac differs from the FASTA"
+        at += h.size
+    assert at == info.l_pac
+    text = IP.Text(fwd)
+    rng = np.random.default_rng(5)
+    rows = np.concatenate([rng.integers(1, info.seq_len - 1, 120_000), np.arange(2 ** 32 - 1500, 2 ** 32 + 1500)]).astype(np.int64)
+    bwt_all = ctx.bwt_syms_chunked()
+    primary = int(info.primary)
+
+    def bwt_lookup(r):
+        r = np.asarray(r, dtype=np.int64)
+        out = bwt_all[np.minimum(r - (r >= primary), bwt_all.size - 1)].astype(np.int16)
+        out[r == primary] = 255
+        return out
+    seen = IP.check_index(text, rows, lambda r: ctx.sa_lookup(r), bwt_lookup, primary, [int(info.L2[c]) for c in range(5)])
+    assert seen["pairs"] == rows.size and seen["above_2_32"] > 1000
+    assert seen["long_lcp"] > 1000 and seen["max_lcp"] > 500       # pairs inside the 2 kb two-copy segments: what only the late doubling rounds order
     P = np.array(bench.PROFILE)
     P[3, 1], P[3, 3] = 0.12, 0.87
 
@@ -79,7 +112,7 @@ def test_parity_and_round_trip_above_2_pow_32_rows(tmp_path):
     sim = dict(codes=rd, lens=np.full(n_reads, L, dtype=np.int32), quals=np.full((n_reads, L), 73, dtype=np.uint8))
     fq = str(tmp_path / "r.fq")
     S.write_fastq(fq, sim, names=["r%d" % i for i in range(n_reads)])
-    oix = orc.Index.from_parts(fa, ctx.bwt_syms_chunked(), info.primary, ctx.sa_samples())
+    oix = orc.Index.from_parts(fa, bwt_all, info.primary, ctx.sa_samples())     # adopted -- and checked against the text above
     osam, gsam = str(tmp_path / "o.sam"), str(tmp_path / "g.sam")
     oix.map_fastq(orc.profile_opt(P, bench.INS_RATE, bench.DEL_RATE, -1), fq, osam, n_threads=16)
     b = ctx.batch_from_codes(rd)
