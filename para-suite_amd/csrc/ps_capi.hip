@@ -330,7 +330,7 @@ int ps_batch_kstats(ps_batch *b, int which, ps_kstats *o)
 // with its own stream and workspace.  Two workers on one device were measured SLOWER end to end (4.6 s against 4.2 s for
 // 10 M reads): two persistent search kernels share the CUs evenly instead of one refilling the other's tail, the later
 // stages of one piece starve under the other's kernel, and the second 69 GB workspace costs its allocation.  The piece size
-// follows from the input: at least two pieces per worker, at most PS_CHUNK_MB (default 400 MB) of text each.
+// follows from the input: at least two pieces per worker, at most 400 MB of text each; PS_CHUNK_MB states a fixed size.
 // Pieces go to whichever worker is free; the one sequential thing, the tie-break stream, is handed from piece to piece in
 // input order (only the reads whose draw count is data dependent sit on that chain), so the SAM does not depend on the cut,
 // on the number of workers or on the number of devices.  A finished piece gives its device memory back at once and at most
@@ -368,8 +368,10 @@ int ps_map(int threads, const char *mm, const char *error_profile, const char *i
         const int G = (int)devs.size();
         int n_workers = 0; for (int w : dev_workers) n_workers += w;
         // ---- piece size from the input
-        size_t chunk_bytes = (size_t)400 << 20;
-        if (const char *e = std::getenv("PS_CHUNK_MB")) chunk_bytes = (size_t)std::max(1, std::atoi(e)) << 20;   // stated: taken as it is
+        // few, large pieces: every search launch ends with its longest read (a 0.44 M-read piece took 243 ms, 10 M reads in one launch
+        // 1.4 s), so six growing pieces cost 2.5 s of search where three cost 1.8 s
+        size_t chunk_bytes = (size_t)400 << 20, first_bytes = 0;
+        if (const char *e = std::getenv("PS_CHUNK_MB")) { chunk_bytes = (size_t)std::max(1, std::atoi(e)) << 20; first_bytes = 0; }   // stated: taken as it is
         else {
             FILE *f = std::fopen(fastq, "rb");
             if (f) {
@@ -402,7 +404,7 @@ int ps_map(int threads, const char *mm, const char *error_profile, const char *i
         const size_t done_cap = (size_t)n_workers + 2;   // finished pieces that may wait for the writer
         std::vector<int> index_state((size_t)G, 0);      // 0 not there, 1 resident
         auto fail_all = [&](const std::string &m) { { std::lock_guard<std::mutex> l(mu); if (!failed) { failed = true; msg = m; } } cv.notify_all(); parsed.abort(); };
-        double t_parse = 0, t_write = 0, t_index = 0, t_index_all = 0; std::vector<double> t_gpu((size_t)n_workers, 0.0);
+        double t_parse = 0, t_write = 0, t_release = 0, t_index = 0, t_index_all = 0; std::vector<double> t_gpu((size_t)n_workers, 0.0);
         int64_t n_reads = 0, n_pieces = 0;
         // ---- parser (starts at once)
         std::thread parser([&]() {
@@ -411,7 +413,7 @@ int ps_map(int threads, const char *mm, const char *error_profile, const char *i
                 load_reads_chunked(fastq, std::max(1, nthr / 2), chunk_bytes, [&](ReadSet &&rs) {
                     Piece p; p.seq = seq++; p.b = batch_prepare(&xs[0]->c, std::move(rs), std::max(1, nthr / 2));     // host only
                     parsed.push(std::move(p));
-                });
+                }, first_bytes);
                 t_parse = since();
             } catch (const std::exception &e) { fail_all(e.what()); }
             parsed.close();
@@ -436,6 +438,9 @@ int ps_map(int threads, const char *mm, const char *error_profile, const char *i
                     first = false;
                     { std::lock_guard<std::mutex> l(mu); ++write_next; }
                     cv.notify_all();
+                    const auto t1 = std::chrono::steady_clock::now();
+                    b.reset();                                         // pinned record buffers, the reads: released here, not on the GPU worker's time
+                    t_release += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
                 }
                 if (first) {                      // no reads at all: an empty file
                     FILE *f = std::fopen(out_sam, "wb");
@@ -510,17 +515,20 @@ int ps_map(int threads, const char *mm, const char *error_profile, const char *i
         if (have_index) { int slot = 0; for (int g = 0; g < G; ++g) for (int j = 0; j < dev_workers[g]; ++j) workers.emplace_back(worker_exit, g, j, slot++); }
         else { std::lock_guard<std::mutex> l(mu); workers_left = 0; }
         for (auto &t : workers) t.join();
+        const double t_workers = since();
         cv.notify_all();
         parsed.abort();                           // a parser still waiting to hand over a piece must not wait forever
         parser.join(); writer.join();
+        const double t_written = since();
         done.clear();
         close_all();
+        const double t_closed = since();
         if (failed) return fail(msg);
         if (verbose) {
             double busy = 0; for (double v : t_gpu) busy += v;
             std::fprintf(stderr, "[parasuite-hip] ps_map: %lld reads in %lld piece(s) of <= %.0f MB, %d device(s) x %d worker(s), %.3f s; index resident after %.3f s (all devices %.3f s), "
-                                 "parser done after %.3f s, GPU stages busy %.3f s (summed over workers), SAM writer busy %.3f s\n", (long long)n_reads, (long long)n_pieces, chunk_bytes / 1048576.0,
-                                 G, dev_workers[0], since(), t_index, t_index_all, t_parse, busy, t_write);
+                                 "parser done after %.3f s, GPU stages busy %.3f s (summed over workers) and done after %.3f s, SAM writer busy %.3f s (+ %.3f s releasing pieces) and done after %.3f s, contexts closed after %.3f s\n", (long long)n_reads, (long long)n_pieces, chunk_bytes / 1048576.0,
+                                 G, dev_workers[0], since(), t_index, t_index_all, t_parse, busy, t_workers, t_write, t_release, t_written, t_closed);
         }
         return 0;
     PS_CATCH_INT

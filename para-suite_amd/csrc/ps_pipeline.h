@@ -18,7 +18,7 @@ struct ReadSet {
     const char *name(int64_t i, size_t &l) const { l = (size_t)(name_off[i + 1] - name_off[i]); return names.data() + name_off[i]; }
 };
 void load_reads(const char *path, ReadSet &rs, int threads = 1); // FASTQ or FASTA
-void load_reads_chunked(const char *path, int threads, size_t chunk_bytes, const std::function<void(ReadSet &&)> &sink);
+void load_reads_chunked(const char *path, int threads, size_t chunk_bytes, const std::function<void(ReadSet &&)> &sink, size_t first_bytes = 0);
 void reads_from_codes(int64_t n, int len, const uint8_t *codes, ReadSet &rs);
 
 static const int PS_HIT_CIGAR = 8;

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cctype>
 #include <cmath>
@@ -18,6 +19,8 @@
 #include <cstring>
 #include <functional>
 #include <thread>
+#include <fcntl.h>
+#include <unistd.h>
 #include "ps_pipeline.h"
 #include "ps_core.h"
 
@@ -258,18 +261,20 @@ void load_reads(const char *path, ReadSet &rs, int threads)
     parse_span(buf.data(), 0, buf.size() - 1, threads, rs);
 }
 
-// The same input in pieces of about chunk_bytes (whole records), in order; sink(piece) may block.  The file is STREAMED:
+// The same input in pieces of about chunk_bytes (whole records; the first of first_bytes, doubling), in order; sink(piece) may block.  The file is STREAMED:
 // one window of chunk_bytes (plus the unfinished record carried over from the window before) is in memory at a time,
 // cut at the last record start that verifies; a window in which none does (records larger than the window) grows.
-void load_reads_chunked(const char *path, int threads, size_t chunk_bytes, const std::function<void(ReadSet &&)> &sink)
+void load_reads_chunked(const char *path, int threads, size_t chunk_bytes, const std::function<void(ReadSet &&)> &sink, size_t first_bytes)
 {
     FILE *f = std::fopen(path, "rb");
     if (!f) throw Error(std::string("cannot open reads ") + path);
     struct Closer { FILE *f; ~Closer() { std::fclose(f); } } closer{f};
     if (chunk_bytes < 4096) chunk_bytes = 4096;
+    // the first window may be smaller (the stages behind the parser start sooner), the following ones double up to chunk_bytes
+    size_t cur = first_bytes && first_bytes < chunk_bytes ? std::max<size_t>(first_bytes, 4096) : chunk_bytes;
     std::vector<char> buf; size_t have = 0; bool eof = false; char mark = 0;
     while (!eof || have) {
-        size_t want = chunk_bytes > have ? chunk_bytes : have + chunk_bytes;      // grow when the carry-over alone fills a window
+        size_t want = cur > have ? cur : have + cur;      // grow when the carry-over alone fills a window
         buf.resize(want + 1);
         while (!eof && have < want) {
             const size_t got = std::fread(buf.data() + have, 1, want - have, f);
@@ -289,7 +294,7 @@ void load_reads_chunked(const char *path, int threads, size_t chunk_bytes, const
         if (cut) {
             ReadSet rs;
             parse_span(buf.data(), 0, cut, threads, rs);
-            if (rs.n) sink(std::move(rs));
+            if (rs.n) { sink(std::move(rs)); cur = std::min(chunk_bytes, cur * 2); }
         }
         std::memmove(buf.data(), buf.data() + cut, have - cut);
         have -= cut;
@@ -1215,7 +1220,14 @@ void Batch::hit_of(int64_t g, Hit &h) const
 
 // ------------------------------------------------------------------ SAM -------
 static inline int host_pac(const std::vector<uint8_t> &pac, int64_t p) { return (pac[(size_t)p >> 2] >> ((~p & 3) << 1)) & 3; }
-static void put_int(std::string &o, long v) { char b[24]; int l = std::snprintf(b, sizeof b, "%ld", v); o.append(b, (size_t)l); }
+static void put_int(std::string &o, long v)            // a dozen numbers per SAM line: no snprintf
+{
+    char b[24]; int n = 24;
+    unsigned long u = v < 0 ? 0ul - (unsigned long)v : (unsigned long)v;
+    do { b[--n] = (char)('0' + u % 10); u /= 10; } while (u);
+    if (v < 0) b[--n] = '-';
+    o.append(b + n, (size_t)(24 - n));
+}
 static void put_cigar(std::string &o, int n, const uint32_t *c, int len)
 {
     if (n) for (int j = 0; j < n; ++j) { put_int(o, c[j] >> 4); o.push_back("MIDS"[c[j] & 0xf]); }
@@ -1319,42 +1331,57 @@ static void sam_line(const Batch &b, int64_t g, std::string &o)
 void batch_write_sam(Batch &b, const char *path, bool header, const char *pg_line, int threads, bool append)
 {
     if (!b.located) throw Error("write_sam before locate");
-    FILE *f = std::fopen(path, append ? "ab" : "wb");
-    if (!f) throw Error(std::string("cannot write ") + path);
+    const int fd = ::open(path, O_WRONLY | O_CREAT | (append ? 0 : O_TRUNC), 0644);
+    if (fd < 0) throw Error(std::string("cannot write ") + path);
+    struct Closer { int fd; bool done = false; ~Closer() { if (!done) ::close(fd); } } closer{fd};
+    off_t at = append ? ::lseek(fd, 0, SEEK_END) : 0;
+    if (at < 0) throw Error(std::string("cannot seek in ") + path);
+    auto put = [&](const char *p, size_t n, off_t where) {           // the whole buffer at its place in the file
+        while (n) { const ssize_t w = ::pwrite(fd, p, n, where); if (w <= 0) return false; p += w; n -= (size_t)w; where += w; }
+        return true;
+    };
     if (header) {
-        for (const Contig &c : b.ctx->ix.ref.contigs) std::fprintf(f, "@SQ\tSN:%s\tLN:%d\n", c.name.c_str(), c.len);
-        if (pg_line && pg_line[0]) std::fprintf(f, "%s\n", pg_line);
+        std::string h; char line[512];
+        for (const Contig &c : b.ctx->ix.ref.contigs) { std::snprintf(line, sizeof line, "@SQ\tSN:%s\tLN:%d\n", c.name.c_str(), c.len); h += line; }
+        if (pg_line && pg_line[0]) { h += pg_line; h += "\n"; }
+        if (!put(h.data(), h.size(), at)) throw Error(std::string("short write on ") + path);
+        at += (off_t)h.size();
     }
     const int64_t N = b.rs.n;
     if (threads < 1) threads = 1;
     if (threads > 64) threads = 64;
-    // rounds of threads x 64k reads: the text of a round is written by one I/O thread while the next round is formatted
+    // rounds of threads x 64k reads: every thread formats its range; the text of a round is then written -- each buffer at its
+    // own offset (pwrite), by a few I/O threads side by side -- while the next round is formatted.  (One writer thread managed
+    // ~1 GB/s and was the slowest stage of ps_map at 2 GB of SAM per 10 M reads.)
     const int64_t chunk = 1 << 16;
     std::vector<std::string> bufs[2] = {std::vector<std::string>((size_t)threads), std::vector<std::string>((size_t)threads)};
-    std::thread io; bool io_ok = true;
+    std::vector<off_t> where[2] = {std::vector<off_t>((size_t)threads, 0), std::vector<off_t>((size_t)threads, 0)};
+    std::thread io; std::atomic<bool> io_ok{true};
+    const int n_io = std::max(1, std::min(4, threads));
     int which = 0;
     for (int64_t base = 0; base < N; base += chunk * threads, which ^= 1) {
-        std::vector<std::string> &out = bufs[which];          // the I/O thread may still hold the other set
-        auto work = [&](int t) {
+        std::vector<std::string> &out = bufs[which];          // the I/O threads may still hold the other set
+        auto fmt = [&](int t) {
             int64_t g0 = base + chunk * t, g1 = std::min(N, g0 + chunk);
             std::string &o = out[t];
             o.clear();
             if (g0 < g1) o.reserve((size_t)(g1 - g0) * 256);
             for (int64_t g = g0; g < g1; ++g) sam_line(b, g, o);
         };
-        std::vector<std::thread> th;
-        for (int t = 1; t < threads; ++t) th.emplace_back(work, t);
-        work(0);
-        for (auto &x : th) x.join();
+        { std::vector<std::thread> th; for (int t = 1; t < threads; ++t) th.emplace_back(fmt, t); fmt(0); for (auto &x : th) x.join(); }
         if (io.joinable()) io.join();
         if (!io_ok) break;
-        io = std::thread([&out, f, &io_ok]() {
-            for (auto &o : out) if (!o.empty() && std::fwrite(o.data(), 1, o.size(), f) != o.size()) { io_ok = false; return; }
+        std::vector<off_t> &wh = where[which];
+        for (int t = 0; t < threads; ++t) { wh[t] = at; at += (off_t)out[t].size(); }
+        io = std::thread([&out, &wh, &put, &io_ok, n_io, threads]() {
+            auto part = [&](int k) { for (int t = k; t < threads; t += n_io) if (!out[t].empty() && !put(out[t].data(), out[t].size(), wh[t])) io_ok = false; };
+            std::vector<std::thread> th; for (int k = 1; k < n_io; ++k) th.emplace_back(part, k); part(0); for (auto &x : th) x.join();
         });
     }
     if (io.joinable()) io.join();
-    if (!io_ok) { std::fclose(f); throw Error(std::string("short write on ") + path); }
-    if (std::fclose(f) != 0) throw Error(std::string("cannot close ") + path);
+    if (!io_ok) throw Error(std::string("short write on ") + path);
+    closer.done = true;
+    if (::close(fd) != 0) throw Error(std::string("cannot close ") + path);
 }
 
 }  // namespace ps
