@@ -508,6 +508,8 @@ static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases
     a.alns = alns; a.aln_cap = aln_cap; a.n_aln = n_aln; a.status = status;
     a.pool = pool; a.pool_cap = pool_cap; a.heads = heads; a.wide = wide ? 1 : 0; a.stats = b.d_stats.p + 1;
     a.queue = queue; a.fetch_min = ctx->fetch_min; a.hit_min = ctx->hit_min;
+    if (const char *e = std::getenv("PS_FETCH_MIN")) a.fetch_min = std::max(1, std::atoi(e));       // tuning: read at every launch
+    if (const char *e = std::getenv("PS_HIT_MIN")) a.hit_min = std::max(1, std::atoi(e));
     if (!wide && pool_cap < 65535 && ctx->n_big > 0) {         // large slots for the reads that outgrow their private slice
         a.big_cap = 65535; a.n_big = (uint32_t)std::min<int64_t>(ctx->n_big, std::max(64, n));
         a.big_pool = wk->ws_get<uint8_t>("big_pool", (size_t)a.n_big * a.big_cap * 16);
