@@ -335,11 +335,10 @@ PS_HD int seq_at(const BtMem &m, const BtLane &L, int j, int len, int max_len)
     return ((nw >> (p & 31)) & 1u) ? 4 : 3 - (int)b;
 }
 
-// The stack of one lane.  NARROW (tiers 1-2): 16-byte entries, bump allocation, bucket heads in LDS --
+// The stack of one lane.  NARROW (tiers 1-2; ps_narrow.h): 16-byte entries, bump allocation, bucket heads in LDS --
 // one 16-byte global store per push and one 16-byte load per pop.  WIDE (last tier, up to the 2,000,000
-// live entries upstream allows): 32-byte entries with a free list and heads in global memory.
-struct Entry16 { uint32_t k, l, a, b; };   // k, l: low words; bit 32 of each sits in b (bits 3 and 7)
-PS_HD uint32_t e16_hi(bwtint k, bwtint l) { return ((uint32_t)(k >> 32) << 3) | ((uint32_t)(l >> 32) << 7); }
+// live entries upstream allows; below): 32-byte entries with a free list and heads in global memory.
+struct Entry16 { uint32_t k, l, a, b; };   // narrow entry: interval relative to its symbol's rows, packed counts, next link (ps_narrow.h)
 static const uint32_t PS_NIL16 = 0xFFFFu;
 
 PS_HD bool bm_test(const BtLane &L, int b) { return (((b & 64) ? L.bm1 : L.bm0) >> (b & 63)) & 1ull; }
@@ -357,7 +356,11 @@ PS_HD void store16(Entry16 *dst, const Entry16 &e)
 {
 #ifdef __HIP_DEVICE_COMPILE__
     ps_u32x4 v; v.x = e.k; v.y = e.l; v.z = e.a; v.w = e.b;
+#if defined(PS_PUSH_NT) && PS_PUSH_NT
+    __builtin_nontemporal_store(v, PS_AS_GLOBAL_W(ps_u32x4, dst));
+#else
     *PS_AS_GLOBAL_W(ps_u32x4, dst) = v;
+#endif
 #else
     *dst = e;
 #endif
@@ -415,92 +418,21 @@ PS_HD void bt_push_wide(const BtHot &a, BtLane &L, BtMem &m, bool want, int i, b
     ++L.n_stack; ++L.st.pushes;
 }
 
-// ---- lean pushes of the narrow stack (the hot path).  The caller has checked once per expansion that nine
-// free slots remain and make_model() guarantees score < 64 buckets for this variant, so a push is: read the
-// bucket head (LDS), one 16-byte store, write the head, three register updates.
-PS_HD uint32_t e16_a(int i, bool is_diff, int n_mm, int state, int n_gapo, int n_gape)
-{
-    return (uint32_t)i | ((uint32_t)(is_diff ? i : 0) << 8) | ((uint32_t)n_mm << 16) |
-           (((uint32_t)state | ((uint32_t)n_gapo << 2) | ((uint32_t)n_gape << 5)) << 24);
-}
-PS_HD uint32_t e16_b(int n_ins, int n_del, int score) { return (uint32_t)n_ins | ((uint32_t)n_del << 4) | ((uint32_t)score << 8); }
-PS_HD uint32_t slot16(BtLane &L, bool go)          // slot for one entry: the one popped last first, then fresh ones
-{
-    const bool reuse = L.free_head != PS_NIL;
-    const uint32_t idx = reuse ? L.free_head : L.bump;
-    L.bump += (go && !reuse) ? 1u : 0u;
-    L.free_head = go ? PS_NIL : L.free_head;
-    return idx;
-}
-PS_HD void push16(BtLane &L, BtMem &m, bool go, bwtint k, bwtint l, uint32_t wa, uint32_t wb, int score)
-{
-    const unsigned long long bit = 1ull << score;
-    const uint32_t idx = slot16(L, go);
-    if (go) {
-        const uint32_t next = (L.bm0 & bit) ? (uint32_t)m.heads16[score] : PS_NIL16;
-        Entry16 e; e.k = (uint32_t)k; e.l = (uint32_t)l; e.a = wa; e.b = wb | (next << 16) | e16_hi(k, l);
-        store16(reinterpret_cast<Entry16 *>(m.pool) + idx, e);
-        m.heads16[score] = (uint16_t)idx;
-    }
-    L.bm0 |= go ? bit : 0ull;
-    L.n_stack += go ? 1 : 0; L.st.pushes += go ? 1u : 0u;
-}
-// up to four children that differ only in their interval (the deletion children): one head read, one head write.
-// Child c covers rows [L2[c]+ck[c]+1, L2[c]+cl[c]], non-empty iff ck[c] < cl[c].
-PS_HD void push16_group(BtLane &L, BtMem &m, bool go_all, const BtHot &ix, const uint32_t ck[4], const uint32_t cl[4], uint32_t wa, uint32_t wb, int score)
-{
-    const unsigned long long bit = 1ull << score;
-    bool any = false;
-    uint32_t next = PS_NIL16;
-    if (go_all) next = (L.bm0 & bit) ? (uint32_t)m.heads16[score] : PS_NIL16;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const bool go = go_all && ck[j] < cl[j];
-        const uint32_t idx = slot16(L, go);
-        if (go) {
-            const bwtint k = ix.L2(j) + ck[j] + 1, l = ix.L2(j) + cl[j];
-            Entry16 e; e.k = (uint32_t)k; e.l = (uint32_t)l; e.a = wa; e.b = wb | (next << 16) | e16_hi(k, l);
-            store16(reinterpret_cast<Entry16 *>(m.pool) + idx, e);
-            next = idx;
-        }
-        any = any || go;
-        L.n_stack += go ? 1 : 0; L.st.pushes += go ? 1u : 0u;
-    }
-    if (any) m.heads16[score] = (uint16_t)next;
-    L.bm0 |= any ? bit : 0ull;
-}
-
 // pop the newest entry of the lowest non-empty score bucket into the lane's current-entry registers
-template <bool WIDE>
+// (wide tier; the narrow tiers' pop is nt_pop in ps_narrow.h)
 PS_HD void bt_pop(const BtHot &a, BtLane &L, BtMem &m)
 {
     const int b = bm_first(L);
-    if (WIDE) {
-        Entry *pool = reinterpret_cast<Entry *>(m.pool);
-        uint32_t h = m.heads[b];
-        Entry e;
-        load_entry(&pool[h], e);
-        if (e.next == PS_NIL) bm_clr(L, b); else m.heads[b] = e.next;
-        pool[h].next = L.free_head; L.free_head = h;
-        L.k = e.k; L.l = e.l; L.i = e.i; L.score = e.score; L.units = e.units;
-        L.n_mm = e.n_mm; L.n_gapo = e.n_gapo; L.n_gape = e.n_gape; L.n_ins = e.n_ins; L.n_del = e.n_del;
-        L.state = e.state; L.ldp = e.last_diff_pos;
-    } else {
-        Entry16 e;
-        const uint32_t h = m.heads16[b];
-        load16(reinterpret_cast<const Entry16 *>(m.pool) + h, e);
-        L.free_head = h;
-        const uint32_t next = e.b >> 16;
-        if (next == PS_NIL16) bm_clr(L, b); else m.heads16[b] = (uint16_t)next;
-        L.k = (bwtint)e.k | ((bwtint)((e.b >> 3) & 1u) << 32); L.l = (bwtint)e.l | ((bwtint)((e.b >> 7) & 1u) << 32);
-        L.i = (int)(e.a & 0xff); L.ldp = (int)((e.a >> 8) & 0xff); L.n_mm = (int)((e.a >> 16) & 0xff);
-        const uint32_t g = e.a >> 24;
-        L.state = (int)(g & 3); L.n_gapo = (int)((g >> 2) & 7); L.n_gape = (int)(g >> 5);
-        L.n_ins = (int)(e.b & 7); L.n_del = (int)((e.b >> 4) & 7);
-        L.score = (int)((e.b >> 8) & 0xff);
-        // units are not stored: profile mode has units == score, stock counts every edit as one unit
-        L.units = a.profile() ? L.score : L.n_mm + L.n_gapo + (a.mode_gape() ? L.n_gape : 0);
-    }
+    Entry *pool = reinterpret_cast<Entry *>(m.pool);
+    uint32_t h = m.heads[b];
+    Entry e;
+    load_entry(&pool[h], e);
+    if (e.next == PS_NIL) bm_clr(L, b); else m.heads[b] = e.next;
+    pool[h].next = L.free_head; L.free_head = h;
+    L.k = e.k; L.l = e.l; L.i = e.i; L.score = e.score; L.units = e.units;
+    L.n_mm = e.n_mm; L.n_gapo = e.n_gapo; L.n_gape = e.n_gape; L.n_ins = e.n_ins; L.n_del = e.n_del;
+    L.state = e.state; L.ldp = e.last_diff_pos;
+    (void)a;
     --L.n_stack; ++L.st.pops;
 }
 
@@ -602,7 +534,7 @@ PS_COLD bool bt_fetch(const BtArgs &a, BtLane &L, BtMem &m, int fetch_r)
 // now (stay idle), >= n_reads = the input is exhausted (retire), else the read index.
 // serve_hit: lanes that reached a hit (M_HIT) record it now; the kernel batches this rare, long path over
 // several lanes of a wave instead of running it for one lane at a time.
-template <bool WIDE>
+// (the wide tier; the narrow tiers run nt_iter, ps_narrow.h.)
 PS_HD void bt_iter(const BtArgs &a, const BtHot &h, BtLane &L, BtMem &m, int fetch_r, bool serve_hit)
 {
     if (L.mode == M_EXIT || L.mode == M_GROW) return;   // retired lane / lane waiting for a larger stack: nothing to do here
@@ -625,14 +557,9 @@ PS_HD void bt_iter(const BtArgs &a, const BtHot &h, BtLane &L, BtMem &m, int fet
 #pragma unroll 1
         for (int tries = 0; tries < PS_POP_TRIES; ++tries) {
             int n_virtual = L.n_stack + (L.have_cur ? 1 : 0);
-            if (!WIDE && L.n_phantom && (long long)n_virtual + (long long)L.n_phantom > (long long)h.max_entries) {
-                // with the skipped children counted the stack-size stop rule might have fired: the exact count is
-                // only kept by the wide tier, which stores every child
-                L.status = RS_OVERFLOW_POOL; bt_finish_read(a, L); return;
-            }
             if (n_virtual == 0 || n_virtual > (int)h.max_entries || L.status != RS_OK) { bt_finish_read(a, L); return; }
             if (L.have_cur) L.have_cur = false;
-            else bt_pop<WIDE>(h, L, m);
+            else bt_pop(h, L, m);
             if (L.score > L.best_score + h.s_stop()) { bt_finish_read(a, L); return; }
             const int rem = L.max_units - L.units;
             if (rem < 0) continue;
@@ -693,62 +620,6 @@ PS_HD void bt_iter(const BtArgs &a, const BtHot &h, BtLane &L, BtMem &m, int fet
         const int tmp = e_go + e_ge;
         const int s = seq_at(m, L, i, len, max_len);
         const bool gap_ok = allow_diff && i >= h.indel_end_skip() + tmp && len - i >= h.indel_end_skip() + tmp;
-        if (!WIDE) {
-            // ---- narrow stack: lean pushes ----
-            if (L.bump + 9u > L.cap) {       // stack full: ask for a large slot once; if that is full too, the read goes to the next tier
-                if (L.cap == h.pool_cap && h.has_big()) { L.mode = M_GROW; return; }
-                L.status = RS_OVERFLOW_POOL; L.mode = M_POP; return;
-            }
-            const bool from_m = e_st == ST_M, from_i = e_st == ST_I, from_d = e_st == ST_D;
-            // A child is popped only to be dropped when the budget left after it cannot pay for the differences its
-            // remaining bases need at least (the check every pop starts with).  The budget only ever shrinks, so such
-            // a child is dropped whenever it is popped: it is not stored at all, only counted (n_phantom) for the
-            // stack-size stop rule.  In profile mode this is about half of all pops.
-            const uint32_t inv = h.inv_c_min;
-            const uint32_t s_word = cost_word(h.s_pk, s), u_word = cost_word(h.u_pk, s);   // this read base against each text symbol
-            uint32_t phantom = 0;
-            // insertion child: opens from M, extends from I
-            {
-                const bool open = from_m && e_go < h.max_gapo(), ext = from_i && e_ge < h.max_gape();
-                const int sc = e_sc + (open ? h.s_gapo_ins() : h.s_gape()), un = e_un + (open ? h.u_gapo_ins() : h.u_gape());
-                const bool cand = gap_ok && (open || ext) && un <= L.max_units;
-                const bool go = cand && (int)(((uint32_t)(L.max_units - un) * inv) >> 16) >= bnd_same;
-                phantom += (cand && !go) ? 1u : 0u;
-                push16(L, m, go, ek, el, e16_a(i, true, e_mm, ST_I, e_go + (open ? 1 : 0), e_ge + (open ? 0 : 1)), e16_b(e_ni + 1, e_nd, sc), sc);
-            }
-            // deletion children: open from M, extend from D; the four share score, counts and position
-            {
-                const bool open = from_m && e_go < h.max_gapo();
-                const bool ext = from_d && e_ge < h.max_gape() && ((e_ge + e_go) * h.u_tight() < L.max_units || occ < (bwtint)h.max_del_occ());
-                const int sc = e_sc + (open ? h.s_gapo_del() : h.s_gape()), un = e_un + (open ? h.u_gapo_del() : h.u_gape());
-                const bool cand = gap_ok && (open || ext) && un <= L.max_units;
-                const bool go = cand && (int)(((uint32_t)(L.max_units - un) * inv) >> 16) >= bnd_del;
-                if (cand && !go) phantom += (ck[0] < cl[0]) + (ck[1] < cl[1]) + (ck[2] < cl[2]) + (ck[3] < cl[3]);
-                push16_group(L, m, go, h, ck, cl, e16_a(i + 1, true, e_mm, ST_D, e_go + (open ? 1 : 0), e_ge + (open ? 0 : 1)), e16_b(e_ni, e_nd + 1, sc), sc);
-            }
-            L.mode = M_POP;
-            const bool do_mm = allow_diff && allow_M;
-#pragma unroll
-            for (int j = 1; j <= 4; ++j) {
-                const int c = (s + j) & 3;
-                const bool is_mm = (j != 4 || s > 3);
-                const uint32_t okc = sel4(ck, c), olc = sel4(cl, c);
-                const bwtint base = h.L2_dyn(c), k2 = base + okc + 1, l2 = base + olc;
-                const bool ok = okc < olc;
-                if (j < 4 || s > 3) {       // mismatch children (the fourth only for an N in the read)
-                    const int sc = e_sc + (int)((s_word >> (8 * c)) & 0xffu), un = e_un + (int)((u_word >> (8 * c)) & 0xffu);
-                    const bool cand = do_mm && ok && is_mm && un <= L.max_units;
-                    const bool go = cand && (int)(((uint32_t)(L.max_units - un) * inv) >> 16) >= bnd_same;
-                    phantom += (cand && !go) ? 1u : 0u;
-                    push16(L, m, go, k2, l2, e16_a(i, true, e_mm + 1, ST_M, e_go, e_ge), e16_b(e_ni, e_nd, sc), sc);
-                }
-                if (j == 4 && ok && !is_mm && (do_mm || s < 4)) {   // the match child: parent's score, pushed last => the next pop
-                    L.k = k2; L.l = l2; L.i = i; L.state = ST_M; L.ldp = 0; L.have_cur = true;
-                }
-            }
-            L.n_phantom += phantom;
-            return;
-        }
         if (gap_ok) {
             if (e_st == ST_M) {
                 if (e_go < h.max_gapo()) {

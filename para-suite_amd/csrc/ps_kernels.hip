@@ -99,39 +99,26 @@ __device__ __forceinline__ void pin_hot(BtHot &h, const BtHot &k)
     h.inv_c_min = pin32(k.inv_c_min); h.max_entries = pin32(k.max_entries); h.pool_cap = pin32(k.pool_cap); h.n_reads = pin32(k.n_reads); h.big_cap = pin32(k.big_cap);
 }
 
-struct BtLoop {             // loop-level constants of the kernel (same treatment)
-    uint32_t *queue; uint32_t *big_next; uint32_t *big_busy; uint8_t *big_pool;
-    uint32_t n_reads, big_cap, n_big, fetch_min, hit_min;
-};
-
-template <bool WIDE>
-__global__ void __launch_bounds__(256) k_backtrack(const BtArgs *__restrict__ ap, BtHot hk, int lm_stride)
+// The wide tier (last resort: 32-byte entries, free list, bucket heads in HBM, upstream's 2,000,000-entry limit): reads that
+// outgrew both narrow tiers.  Reads are handed out dynamically: search effort differs by orders of magnitude between
+// reads, so a lane takes a new read as soon as it is done.  A wave reserves chunks of PS_Q_CHUNK reads from one global
+// counter (one atomic per chunk) and deals them to its idle lanes by ballot rank; it loads new reads only when fetch_min
+// lanes are idle (or nothing else is running), because the load path is executed by the whole wave.
+__global__ void __launch_bounds__(256) k_backtrack_wide(const BtArgs *__restrict__ ap, BtHot hk, int lm_stride)
 {
     const BtArgs &a = *ap;      // arguments live in device memory: the cold (non-inlined) paths take their address
     BtHot h; pin_hot(h, hk);
-    BtLoop lp;
-    lp.queue = reinterpret_cast<uint32_t *>(pin64(reinterpret_cast<unsigned long long>(a.queue)));
-    lp.big_next = reinterpret_cast<uint32_t *>(pin64(reinterpret_cast<unsigned long long>(a.big_next)));
-    lp.big_busy = reinterpret_cast<uint32_t *>(pin64(reinterpret_cast<unsigned long long>(a.big_busy)));
-    lp.big_pool = reinterpret_cast<uint8_t *>(pin64(reinterpret_cast<unsigned long long>(a.big_pool)));
-    lp.n_reads = pin32((uint32_t)a.n_reads); lp.big_cap = pin32(a.big_cap); lp.n_big = pin32(a.n_big);
-    lp.fetch_min = pin32((uint32_t)a.fetch_min); lp.hit_min = pin32((uint32_t)a.hit_min);
+    uint32_t *const queue = reinterpret_cast<uint32_t *>(pin64(reinterpret_cast<unsigned long long>(a.queue)));
+    const uint32_t n_reads = h.n_reads, fetch_min = pin32((uint32_t)a.fetch_min), hit_min = pin32((uint32_t)a.hit_min);
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane_g = blockIdx.x * blockDim.x + threadIdx.x;
     BtMem m;
-    uint8_t *mine = smem + (size_t)threadIdx.x * lm_stride;
-    bt_mem_bind(m, mine, h.len(), h.seed_len());
-    uint8_t *const pool_private = reinterpret_cast<uint8_t *>(a.pool) + (size_t)lane_g * h.pool_cap * (WIDE ? sizeof(Entry) : sizeof(Entry16));
-    m.pool = pool_private;
-    m.heads = WIDE ? a.heads + (size_t)lane_g * PS_MAX_BUCKETS : nullptr;
+    bt_mem_bind(m, smem + (size_t)threadIdx.x * lm_stride, h.len(), h.seed_len());
+    m.pool = reinterpret_cast<uint8_t *>(a.pool) + (size_t)lane_g * h.pool_cap * sizeof(Entry);
+    m.heads = a.heads + (size_t)lane_g * PS_MAX_BUCKETS;
     BtLane L;
     L.mode = M_FETCH; L.r = 0; L.have_cur = false; L.n_stack = 0; L.status = RS_OK; L.n_aln = 0;
     L.st = {0, 0, 0, 0, 0, 0, 0, 0};
-    // Reads are handed out dynamically: search effort differs by orders of magnitude between reads, so a
-    // lane takes a new read as soon as it is done.  A wave reserves chunks of PS_Q_CHUNK reads from one
-    // global counter (one atomic per chunk) and deals them to its idle lanes by ballot rank; it loads new
-    // reads only when fetch_min lanes are idle (or nothing else is running), because the load path is
-    // executed by the whole wave.
     const int lane = threadIdx.x & 63;
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
     const unsigned long long t_start = wall_clock64();
@@ -139,65 +126,34 @@ __global__ void __launch_bounds__(256) k_backtrack(const BtArgs *__restrict__ ap
     bool exhausted = false;
     for (;;) {
         const bool want = L.mode == M_FETCH;
-        if (!WIDE && want && m.pool != pool_private) {         // read done on a large slot: hand the slot back
-            const unsigned int slot = (unsigned int)((reinterpret_cast<uint8_t *>(m.pool) - lp.big_pool) / ((size_t)lp.big_cap * sizeof(Entry16)));
-            __threadfence();                                   // this lane's stores to the slot land before the next owner's
-            atomicExch(lp.big_busy + slot, 0u);
-            m.pool = pool_private;                             // a new read starts on the lane's private stack slice
-        }
         const unsigned long long wmask = __ballot(want), lmask = __ballot(L.mode != M_EXIT), hmask = __ballot(L.mode == M_HIT);
         if (lmask == 0) break;
         const bool stalled = (wmask | hmask) == lmask;          // nobody can advance without being served
-        const bool serve_hit = hmask != 0 && (__popcll(hmask) >= (int)lp.hit_min || stalled);
+        const bool serve_hit = hmask != 0 && (__popcll(hmask) >= (int)hit_min || stalled);
         int fetch_r = -1;
         if (wmask) {
             const int cnt = __popcll(wmask);
-            if (cnt >= (int)lp.fetch_min || stalled) {
+            if (cnt >= (int)fetch_min || stalled) {
                 const int rank = __popcll(wmask & lane_lt);
                 int served = 0;
                 while (served < cnt) {
                     if (q_next == q_end) {
                         if (exhausted) break;
                         unsigned int base = 0;
-                        if (lane == 0) base = atomicAdd(lp.queue, (unsigned int)PS_Q_CHUNK);
+                        if (lane == 0) base = atomicAdd(queue, (unsigned int)PS_Q_CHUNK);
                         base = (unsigned int)__shfl((int)base, 0, 64);
-                        if (base >= lp.n_reads) { exhausted = true; break; }
+                        if (base >= n_reads) { exhausted = true; break; }
                         q_next = (int)base;
-                        q_end = (int)base + PS_Q_CHUNK < (int)lp.n_reads ? (int)base + PS_Q_CHUNK : (int)lp.n_reads;
+                        q_end = (int)base + PS_Q_CHUNK < (int)n_reads ? (int)base + PS_Q_CHUNK : (int)n_reads;
                     }
                     const int take = q_end - q_next < cnt - served ? q_end - q_next : cnt - served;
                     if (want && rank >= served && rank < served + take) fetch_r = q_next + (rank - served);
                     q_next += take; served += take;
                 }
-                if (want && fetch_r < 0 && exhausted) fetch_r = (int)lp.n_reads;   // nothing left: this lane retires
+                if (want && fetch_r < 0 && exhausted) fetch_r = (int)n_reads;   // nothing left: this lane retires
             }
         }
-        if (!WIDE) {
-            unsigned long long gmask = __ballot(L.mode == M_GROW);
-            while (gmask) {                                    // wave-uniform loop over the lanes that need a larger stack
-                const int src = __ffsll((unsigned long long)gmask) - 1;
-                gmask &= gmask - 1;
-                unsigned int slot = lp.n_big;
-                if (lane == src) {                             // claim a free slot: rotating start, bounded probing
-                    unsigned int at = atomicAdd(lp.big_next, 1u) % lp.n_big;
-                    for (int tries = 0; tries < 256; ++tries) {
-                        if (atomicCAS(lp.big_busy + at, 0u, 1u) == 0u) { slot = at; break; }
-                        at = at + 1u == lp.n_big ? 0u : at + 1u;
-                    }
-                }
-                slot = (unsigned int)__shfl((int)slot, src, 64);
-                const unsigned int n_copy = (unsigned int)__shfl((int)L.bump, src, 64);
-                const unsigned long long from = (unsigned long long)__shfl((long long)reinterpret_cast<unsigned long long>(m.pool), src, 64);
-                if (slot < lp.n_big) {
-                    const uint4 *sp = reinterpret_cast<const uint4 *>(from);
-                    uint4 *dp = reinterpret_cast<uint4 *>(lp.big_pool + (size_t)slot * lp.big_cap * sizeof(Entry16));
-                    for (unsigned int e = (unsigned int)lane; e < n_copy; e += 64u) dp[e] = sp[e];
-                    __threadfence();                           // the copies of all lanes are visible before the owner pops from them
-                    if (lane == src) { m.pool = dp; L.cap = lp.big_cap; L.mode = M_EXPAND; }
-                } else if (lane == src) { L.status = RS_OVERFLOW_POOL; L.mode = M_POP; }
-            }
-        }
-        bt_iter<WIDE>(a, h, L, m, fetch_r, serve_hit);
+        bt_iter(a, h, L, m, fetch_r, serve_hit);
     }
     // how long this wave was busy (160 ns units, summed over waves in the otherwise unused lf field): the mean wave
     // time against the kernel time is the share of the launch spent waiting for the last long reads
@@ -206,8 +162,8 @@ __global__ void __launch_bounds__(256) k_backtrack(const BtArgs *__restrict__ ap
 }
 
 
-// The narrow tiers (16-byte stack entries; ps_narrow.h): same read hand-out and stack growth as above, the lane state
-// packed.  STATS: per-lane counters for the roofline accounting and the per-read profile -- the timed kernel has none.
+// The narrow tiers (16-byte stack entries; ps_narrow.h): the same read hand-out, the lane state packed, and a stack that
+// grows inside the launch: a read that outgrows its private slice moves to one of the large slots (wave-cooperative copy).  STATS: per-lane counters for the roofline accounting and the per-read profile -- the timed kernel has none.
 template <bool STATS>
 __global__ void __launch_bounds__(256, PS_BT_WAVES) k_backtrack_n(const BtArgs *__restrict__ ap, BtHot hk, int lm_stride)
 {
@@ -372,17 +328,16 @@ void launch_width(const WidthArgs &a, hipStream_t s)
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_width, dim3(blocks), dim3(256), 0, s, a);
 }
-bool launch_backtrack(const BtArgs &a, const BtArgs *d_args, int n_blocks, int lm_stride, hipStream_t s, bool stats, int variant)
+bool launch_backtrack(const BtArgs &a, const BtArgs *d_args, int n_blocks, int lm_stride, hipStream_t s, bool stats)
 {
     BtHot h;
     if (!bt_hot_make(a, h)) return false;       // a model field outside its packed range
     (void)hipMemcpyAsync(const_cast<BtArgs *>(d_args), &a, sizeof(BtArgs), hipMemcpyHostToDevice, s);
     const size_t lds = (size_t)256 * lm_stride;
-    const void *fn = a.wide ? reinterpret_cast<const void *>(k_backtrack<true>) : variant == 0 ? reinterpret_cast<const void *>(k_backtrack<false>)
+    const void *fn = a.wide ? reinterpret_cast<const void *>(k_backtrack_wide)
                    : stats ? reinterpret_cast<const void *>(k_backtrack_n<true>) : reinterpret_cast<const void *>(k_backtrack_n<false>);
     if (lds > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (a.wide) hipLaunchKernelGGL(k_backtrack<true>, dim3(n_blocks), dim3(256), lds, s, d_args, h, lm_stride);
-    else if (variant == 0) hipLaunchKernelGGL(k_backtrack<false>, dim3(n_blocks), dim3(256), lds, s, d_args, h, lm_stride);   // round-1 narrow kernel (A/B only)
+    if (a.wide) hipLaunchKernelGGL(k_backtrack_wide, dim3(n_blocks), dim3(256), lds, s, d_args, h, lm_stride);
     else if (stats) hipLaunchKernelGGL(k_backtrack_n<true>, dim3(n_blocks), dim3(256), lds, s, d_args, h, lm_stride);
     else hipLaunchKernelGGL(k_backtrack_n<false>, dim3(n_blocks), dim3(256), lds, s, d_args, h, lm_stride);
     return true;

@@ -1,7 +1,7 @@
 // ps_narrow.h -- the hot loop of the narrow search tiers (16-byte stack entries): what `bwa aln` /
 // `bwa parasuite` compute for /root/reference/src/src/mapping/PARAsuiteMapping.java:63-77 and
 // BWAMapping.java:51-61, one read per lane.  Same search, same visiting order and same results as the wide
-// tier's bt_iter<true> in ps_core.h (and as oracle/ps_oracle.c); what differs is how a lane holds its state:
+// tier's bt_iter in ps_core.h (and as oracle/ps_oracle.c); what differs is how a lane holds its state:
 //
 //  * the current entry stays PACKED in four registers exactly as it sits on the stack (kr, lr, wa, wb), a
 //    child's words are the parent's plus a constant, and a pop is a 16-byte load with nothing to unpack;

@@ -520,8 +520,7 @@ static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases
     uint32_t *riters = nullptr;
     if (ctx->want_read_iters) { riters = wk->ws_get<uint32_t>("riters", (size_t)n * 2); PS_HIP(hipMemsetAsync(riters, 0, (size_t)n * 8, s)); a.read_iters = riters; }
     { EvTimer t(s);
-      const char *ev = std::getenv("PS_BT_VARIANT");
-      if (!launch_backtrack(a, wk->ws_get<BtArgs>("btargs", 1), blocks, lm, s, ctx->want_kstats || ctx->want_read_iters, ev ? std::atoi(ev) : 1)) throw Error("cost model outside the ranges the search kernel packs (gap/score fields must fit a byte)");
+      if (!launch_backtrack(a, wk->ws_get<BtArgs>("btargs", 1), blocks, lm, s, ctx->want_kstats || ctx->want_read_iters)) throw Error("cost model outside the ranges the search kernel packs (gap/score fields must fit a byte)");
       PS_HIP(hipGetLastError());
       const double ms = t.stop(); b.tm.ms_backtrack += ms; ++b.tm.n_backtrack_launches;
       { double t0_ = 0, t1_ = 0; t.span(ctx->ref_event, t0_, t1_); if (b.tm.n_backtrack_launches == 1) b.tm.bt_begin_ms = t0_; b.tm.bt_end_ms = t1_; }

@@ -145,12 +145,12 @@ int hs_aln(void *p, const Model *md, int n_reads, int len, const uint8_t *codes,
                 continue;
             }
             BtLane &L = lanes[t];
-            if (L.mode == M_EXIT) { BtMem mm{}; bt_iter<true>(a, h, L, mm, -1, true); continue; }
+            if (L.mode == M_EXIT) { BtMem mm{}; bt_iter(a, h, L, mm, -1, true); continue; }
             m.pool = priv;
             m.heads = a.heads + (size_t)t * PS_MAX_BUCKETS;
             int fr = -1;
             if (L.mode == M_FETCH) { fr = next[t] < n_reads ? next[t] : n_reads; next[t] += n_lanes; }
-            bt_iter<true>(a, h, L, m, fr, (t & 1) != 0 || L.mode != M_HIT || (L.st.iters & 3) == 0);
+            bt_iter(a, h, L, m, fr, (t & 1) != 0 || L.mode != M_HIT || (L.st.iters & 3) == 0);
             any = true;
         }
     }
@@ -218,7 +218,7 @@ int hs_unit_rows33(void)
         m.pool = wpool.data(); m.heads = heads.data();
         memset(&L, 0, sizeof L); L.free_head = PS_NIL; L.max_units = 100;
         bt_push_wide(aw, L, m, true, 21, k, l, 4, 1, 2, 3, 0, ST_I, true, 11, 11);
-        bt_pop<true>(aw, L, m);
+        bt_pop(aw, L, m);
         if (L.k != k || L.l != l || L.i != 21) return 3;
     }
     for (bwtint sidx : big) {                                  // block addressing
