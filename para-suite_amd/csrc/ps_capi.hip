@@ -196,6 +196,7 @@ ps_ctx *ps_ctx_from_blobs(const char *meta, int64_t meta_len, int device, void *
         PS_HIP(hipMemcpy(ix.ref.pac.data(), ix.pac.p, np, hipMemcpyDeviceToHost));
         ix.refresh_view();
         ix.view.primary = primary; std::memcpy(ix.view.L2, L2, sizeof L2);
+        index_build_jump(ix, nullptr);
         return x;
     } catch (const std::exception &e) { delete x; fail(e.what()); return nullptr; } catch (...) { delete x; fail("unknown error"); return nullptr; }
 }

@@ -256,8 +256,25 @@ PS_HD int lm_bytes(int len, int seed_len, int n_buckets, bool wide)
 // keeps in scalar registers for its whole life (BtArgs itself lives in device memory for the rare, non-inlined
 // paths; reading it inside the loop costs a scalar-cache round trip per field and turns a dynamic L2[c]
 // into a vector load).  Small fields are packed four to a word.
+// ---- jump table: the child intervals of the short strings ------------------------------------------------------
+// A search step at depth d (text symbols consumed so far) needs Occ(k-1, .) and Occ(l, .) of its interval.  Near the root
+// the interval is wide, the two rows lie in different blocks of the BWT (two random 64-byte reads), and there are few distinct
+// intervals: 4^d strings at depth d.  The table holds, for every string of fewer than K symbols, exactly what nt_occ returns
+// for its interval -- eight words {ck[0], cl[0], .. ck[3], cl[3]} (an empty string's slot is all zero: no child) -- so a step
+// at depth < K is ONE 32-byte read, and the upper levels (4^d * 32 bytes: 32 MB at d = 10) come out of L2 / the MALL.  At
+// hg19 size K = 14: 16.3 G of the bench's 38 G steps, which cost 31 G block reads without it (profiles/r02_kernel_experiments.txt);
+// 2.9 GB of the 288.  While a search entry is at depth < K it carries the string's index in its level (kr) and the width of its
+// interval (lr) instead of the interval: the interval itself comes back out of the parent's slot where a hit needs it.
+// Level d starts (4^d - 1) / 3 slots into the table; a string's index is its symbols as base-4 digits, the last consumed lowest.
+static const int PS_JUMP_SLOT_WORDS = 8, PS_JUMP_MAX_LEVELS = 14;
+PS_HD uint32_t jump_level_off(int d) { return 0x55555555u & ((1u << (2 * d)) - 1u); }
+PS_HD size_t jump_words(int levels) { return (size_t)jump_level_off(levels) * PS_JUMP_SLOT_WORDS; }
+// levels worth having: below them an interval is still wider than a fraction of a block on average
+PS_HD int jump_levels_for(bwtint seq_len) { int k = 0; while (k < PS_JUMP_MAX_LEVELS && (seq_len >> (2 * k)) >= 48) ++k; return k; }
+
 struct BtHot {
     const OccBlock *blocks; bwtint primary;
+    const uint32_t *jump; uint32_t jump_levels;
     uint32_t L2lo[4], L2hi;          // C array of the FM index: low words, bit 32 of L2[c] at bit c (bit 4: bit 32 of n, the root's base)
     uint32_t s_pk[5], u_pk[5];       // substitution costs, one word per read symbol (byte c = text symbol)
     uint32_t p0, p1, p2, p3;
@@ -292,6 +309,7 @@ inline bool bt_hot_make(const BtArgs &a, BtHot &h)
 {
     const Model &md = a.md;
     h.blocks = a.ix.blocks; h.primary = a.ix.primary; h.L2hi = 0;
+    h.jump = a.ix.jump; h.jump_levels = a.ix.jump ? (uint32_t)a.ix.jump_levels : 0u;
     for (int c = 0; c < 4; ++c) { h.L2lo[c] = (uint32_t)a.ix.L2[c]; h.L2hi |= (uint32_t)((a.ix.L2[c] >> 32) & 1ull) << c; }
     h.L2hi |= (uint32_t)((a.ix.seq_len >> 32) & 1ull) << 4;
     for (int c = 0; c < 5; ++c) { h.s_pk[c] = md.s_mm_pk[c]; h.u_pk[c] = md.u_mm_pk[c]; }

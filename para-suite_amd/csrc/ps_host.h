@@ -61,14 +61,16 @@ struct Rng48 {
 struct Index {
     RefSeq ref;
     DevBuf<OccBlock> blocks; DevBuf<uint32_t> sa; DevBuf<uint8_t> pac;   // sa: n_sa low words, then the bit-32 plane
+    DevBuf<uint32_t> jump; int jump_levels = 0;                          // jump table (ps_core.h): built on the device after every build / load, never saved
     IndexView view;
     double build_ms = 0;
     int sa_rounds = 0;
     void refresh_view();
     static size_t sa_words(size_t n_sa) { return n_sa + (n_sa + 31) / 32; }
-    size_t device_bytes() const { return blocks.n * sizeof(OccBlock) + sa.n * sizeof(uint32_t) + pac.n; }
+    size_t device_bytes() const { return blocks.n * sizeof(OccBlock) + sa.n * sizeof(uint32_t) + pac.n + jump.n * sizeof(uint32_t); }
 };
 void index_build(const char *fa, Index &ix, hipStream_t s);        // GPU suffix sorting (ps_index.hip)
+void index_build_jump(Index &ix, hipStream_t s);                    // the view must be complete (blocks, primary, L2); PS_JUMP_LEVELS overrides the depth
 void index_save(const Index &ix, const std::string &prefix);
 void index_load(const std::string &prefix, Index &ix, hipStream_t s);
 // a second copy of a resident index on another device, over xGMI (hipMemcpyPeerAsync); the caller has made dst_device current

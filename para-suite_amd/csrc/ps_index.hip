@@ -367,6 +367,19 @@ void Index::refresh_view()
     view.blocks = blocks.p; view.sa = sa.p; view.sa_hi = sa.p + view.n_sa; view.pac = pac.p;
     view.l_pac = (bwtint)ref.l_pac; view.seq_len = (bwtint)(2 * ref.l_pac);
     view.n_blocks = (uint32_t)blocks.n; view.sa_intv = 32;
+    view.jump = jump_levels > 0 ? jump.p : nullptr; view.jump_levels = jump_levels;
+}
+
+void index_build_jump(Index &ix, hipStream_t s)
+{
+    int levels = jump_levels_for(ix.view.seq_len);
+    if (const char *e = std::getenv("PS_JUMP_LEVELS")) levels = std::max(0, std::min(PS_JUMP_MAX_LEVELS, std::atoi(e)));
+    ix.jump_levels = 0; ix.view.jump = nullptr; ix.view.jump_levels = 0;
+    if (levels == 0) return;
+    ix.jump.alloc(jump_words(levels));
+    launch_jump_build(ix.view, ix.jump.p, levels, s);
+    PS_HIP(hipStreamSynchronize(s));
+    ix.jump_levels = levels; ix.view.jump = ix.jump.p; ix.view.jump_levels = levels;
 }
 
 namespace {
@@ -535,6 +548,7 @@ void index_build(const char *fa, Index &ix, hipStream_t s)
     if (ix.view.L2[4] != (bwtint)n) throw Error("index build: symbol counts do not add up");
     for (int j = 0; j < 4; ++j)
         if (ix.view.L2[j + 1] - ix.view.L2[j] != cnt[j]) throw Error("index build: BWT symbol counts differ from the text's");
+    index_build_jump(ix, s);
     ix.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
@@ -647,6 +661,7 @@ void index_load(const std::string &prefix, Index &ix, hipStream_t s)
     bwtint primary = ix.view.primary; bwtint L2[5]; std::memcpy(L2, ix.view.L2, sizeof L2);
     ix.refresh_view();
     ix.view.primary = primary; std::memcpy(ix.view.L2, L2, sizeof L2);
+    index_build_jump(ix, s);
 }
 
 // only what the error-profile stage needs of an index: contigs, holes and the packed forward strand on the device
@@ -660,7 +675,7 @@ void index_load_pac(const std::string &prefix, Index &ix, hipStream_t s)
     ix.view.pac = ix.pac.p; ix.view.l_pac = (bwtint)ix.ref.l_pac;
 }
 
-// The index of one device copied to another: three blobs over xGMI, no file read (ps_map with several devices loads the
+// The index of one device copied to another: its blobs (and the jump table) over xGMI, no file read (ps_map with several devices loads the
 // files once).  Falls back to a copy staged by the runtime when the devices cannot reach each other directly.
 void index_clone(const Index &src, int src_device, Index &dst, int dst_device, hipStream_t s)
 {
@@ -671,6 +686,8 @@ void index_clone(const Index &src, int src_device, Index &dst, int dst_device, h
         if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
     }
     dst.blocks.alloc(src.blocks.n); dst.sa.alloc(src.sa.n); dst.pac.alloc(src.pac.n);
+    dst.jump_levels = src.jump_levels;
+    if (src.jump_levels) { dst.jump.alloc(src.jump.n); PS_HIP(hipMemcpyPeerAsync(dst.jump.p, dst_device, src.jump.p, src_device, src.jump.n * sizeof(uint32_t), s)); }
     PS_HIP(hipMemcpyPeerAsync(dst.blocks.p, dst_device, src.blocks.p, src_device, src.blocks.n * sizeof(OccBlock), s));
     PS_HIP(hipMemcpyPeerAsync(dst.sa.p, dst_device, src.sa.p, src_device, src.sa.n * sizeof(uint32_t), s));
     PS_HIP(hipMemcpyPeerAsync(dst.pac.p, dst_device, src.pac.p, src_device, src.pac.n, s));

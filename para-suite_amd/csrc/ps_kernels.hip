@@ -7,6 +7,8 @@
 // search state in LDS, loops flattened so that every lane of a wave issues its
 // random HBM load in the same iteration.
 #include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdlib>
 #include "ps_core.h"
 #include "ps_narrow.h"
 #include "ps_kernels.h"
@@ -90,6 +92,7 @@ __device__ __forceinline__ void pin_hot(BtHot &h, const BtHot &k)
 {
     h.blocks = reinterpret_cast<const OccBlock *>(pin64(reinterpret_cast<unsigned long long>(k.blocks)));
     h.primary = pin64(k.primary);
+    h.jump = reinterpret_cast<const uint32_t *>(pin64(reinterpret_cast<unsigned long long>(k.jump))); h.jump_levels = pin32(k.jump_levels);
 #pragma unroll
     for (int c = 0; c < 4; ++c) h.L2lo[c] = pin32(k.L2lo[c]);
     h.L2hi = pin32(k.L2hi);
@@ -328,8 +331,31 @@ void launch_width(const WidthArgs &a, hipStream_t s)
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_width, dim3(blocks), dim3(256), 0, s, a);
 }
-bool launch_backtrack(const BtArgs &a, const BtArgs *d_args, int n_blocks, int lm_stride, hipStream_t s, bool stats)
+// ---- jump table (ps_core.h): one thread per string of level d, the levels one after the other ----
+__global__ void __launch_bounds__(256) k_jump_level(BtHot h, uint32_t *table, bwtint seq_len, int d)
 {
+    const uint32_t n = 1u << (2 * d);
+    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) jump_fill_slot(h, table, seq_len, d, s);
+}
+void launch_jump_build(const IndexView &ix, uint32_t *table, int levels, hipStream_t s)
+{
+    BtArgs a{};
+    a.ix = ix; a.ix.jump = nullptr; a.ix.jump_levels = 0;
+    BtHot h;
+    (void)bt_hot_make(a, h);                     // only the index fields are read by the builder
+    for (int d = 0; d < levels; ++d) {
+        const uint32_t n = 1u << (2 * d);
+        const int blocks = (int)std::min<uint32_t>((n + 255u) / 256u, 256u * 16u);
+        hipLaunchKernelGGL(k_jump_level, dim3(blocks), dim3(256), 0, s, h, table, ix.seq_len, d);
+    }
+}
+bool launch_backtrack(const BtArgs &a_in, const BtArgs *d_args, int n_blocks, int lm_stride, hipStream_t s, bool stats)
+{
+    BtArgs a = a_in;
+    // the counting kernel counts the blocks of the plain algorithm (SURVEY.md 8d's figure), the wide tier keeps whole intervals
+    // in its entries: both search without the jump table.  PS_JUMP=0: the timed kernel too (A/B measurements)
+    const char *ej = std::getenv("PS_JUMP");
+    if (stats || a.wide || (ej && std::atoi(ej) == 0)) { a.ix.jump = nullptr; a.ix.jump_levels = 0; }
     BtHot h;
     if (!bt_hot_make(a, h)) return false;       // a model field outside its packed range
     (void)hipMemcpyAsync(const_cast<BtArgs *>(d_args), &a, sizeof(BtArgs), hipMemcpyHostToDevice, s);

@@ -140,6 +140,38 @@ PS_HD void nt_occ(const BtHot &h, uint32_t c, uint32_t kr, uint32_t lr, uint32_t
     if (STATS) { ++st.pairs; if (need_k && bk == bl) ++st.same; }
 }
 
+// text symbols an entry has consumed (its depth in the tree of strings): read bases used, less the inserted ones, plus the deleted
+PS_HD int nt_depth(int len, uint32_t wa, uint32_t wb) { return len - nw_i(wa) - (int)(wb & 7u) + (int)((wb >> 3) & 7u); }
+// the same two results out of the jump table: the entry is at depth d < jump_levels and carries its string's index
+PS_HD void nt_jump(const BtHot &h, int d, uint32_t sidx, uint32_t ck[4], uint32_t cl[4])
+{
+    const uint32_t *sl = h.jump + (size_t)(jump_level_off(d) + sidx) * PS_JUMP_SLOT_WORDS;
+#ifdef __HIP_DEVICE_COMPILE__
+    const ps_u32x4 a = *PS_AS_GLOBAL(ps_u32x4, sl), b = *PS_AS_GLOBAL(ps_u32x4, sl + 4);
+    ck[0] = a.x; cl[0] = a.y; ck[1] = a.z; cl[1] = a.w; ck[2] = b.x; cl[2] = b.y; ck[3] = b.z; cl[3] = b.w;
+#else
+    for (int c = 0; c < 4; ++c) { ck[c] = sl[2 * c]; cl[c] = sl[2 * c + 1]; }
+#endif
+}
+// one slot of the table (the builder: level d is filled after level d - 1).  The string's own interval is child (s & 3) of its
+// parent's slot; the slot holds nt_occ of that interval, computed by nt_occ itself.
+PS_HD void jump_fill_slot(const BtHot &h, uint32_t *table, bwtint seq_len, int d, uint32_t s)
+{
+    uint32_t c = NW_ROOT_C, kr = 0, lr = (uint32_t)seq_len;
+    bool empty = false;
+    if (d > 0) {
+        const uint32_t *ps = table + (size_t)(jump_level_off(d - 1) + (s >> 2)) * PS_JUMP_SLOT_WORDS;
+        c = s & 3u;
+        empty = ps[2 * c] >= ps[2 * c + 1];
+        kr = ps[2 * c] + 1u; lr = ps[2 * c + 1];
+    }
+    uint32_t ck[4] = {0, 0, 0, 0}, cl[4] = {0, 0, 0, 0};
+    LaneStats st;
+    if (!empty) nt_occ<false>(h, c, kr, lr, ck, cl, st);
+    uint32_t *out = table + (size_t)(jump_level_off(d) + s) * PS_JUMP_SLOT_WORDS;
+    for (int j = 0; j < 4; ++j) { out[2 * j] = ck[j]; out[2 * j + 1] = cl[j]; }
+}
+
 // base j of the reverse-complemented read (what the search consumes): 0..3, 4 = N
 PS_HD int nt_seq_at(const BtMem &m, const NLane &L, int j, int len, int max_len)
 {
@@ -161,6 +193,13 @@ PS_COLD void nt_hit(const BtArgs &a, NLane &L, BtMem &m)
 {
     const Model &md = a.md;
     const uint32_t c = nw_c(L.wb);
+    if (a.ix.jump && c != NW_ROOT_C) {           // an entry of the jump table's levels holds (string index, width): its interval is in the parent's slot
+        const int d = nt_depth(nl_len(L), L.wa, L.wb);
+        if (d < a.ix.jump_levels) {
+            const uint32_t *ps = a.ix.jump + (size_t)(jump_level_off(d - 1) + (L.kr >> 2)) * PS_JUMP_SLOT_WORDS;
+            L.kr = ps[2 * c] + 1u; L.lr = ps[2 * c + 1];
+        }
+    }
     const bwtint base = c == NW_ROOT_C ? (a.ix.seq_len & ~(bwtint)0xFFFFFFFFull) : a.ix.L2[c];
     const bwtint k = base + L.kr, l = base + L.lr;
     const int score = nw_score(L.wb), n_gapo = nw_gapo(L.wa);
@@ -339,7 +378,7 @@ PS_HD int nt_head(const BtArgs &a, const BtHot &h, NLane &L, LaneStats &st, BtMe
 }
 
 // what a lane carries from the memory step to the tail
-struct NtStep { uint32_t ck[4], cl[4]; uint32_t cw_i, cw_im1, cs_i, cs_im1; int s, i; bool in_seed; };
+struct NtStep { uint32_t ck[4], cl[4]; uint32_t cw_i, cw_im1, cs_i, cs_im1; int s, i; bool in_seed, tm, ctm; };     // tm / ctm: the entry / its children are in the jump table's levels
 
 template <bool STATS>
 PS_HD void nt_step_occ(const BtHot &h, NLane &L, LaneStats &st, BtMem &m, NtStep &q)
@@ -354,7 +393,10 @@ PS_HD void nt_step_occ(const BtHot &h, NLane &L, LaneStats &st, BtMem &m, NtStep
     q.in_seed = h.use_seed() && ii > 0;
     q.cs_i = q.in_seed ? m.csw[ii] : 0u; q.cs_im1 = q.in_seed ? m.csw[ii - 1] : 0u;
     q.s = nt_seq_at(m, L, i, len, max_len);
-    nt_occ<STATS>(h, nw_c(L.wb), L.kr, L.lr, q.ck, q.cl, st);
+    const int depth = nt_depth(len, L.wa, L.wb);
+    q.tm = depth < (int)h.jump_levels; q.ctm = depth + 1 < (int)h.jump_levels;
+    if (q.tm) nt_jump(h, depth, L.kr, q.ck, q.cl);
+    else nt_occ<STATS>(h, nw_c(L.wb), L.kr, L.lr, q.ck, q.cl, st);
 }
 
 template <bool STATS>
@@ -362,7 +404,7 @@ PS_HD void nt_tail(const BtHot &h, NLane &L, LaneStats &st, BtMem &m, const NtSt
 {
     const int len = nl_len(L), i = q.i, s = q.s;
     const uint32_t cw_i = q.cw_i, cw_im1 = q.cw_im1, cs_i = q.cs_i, cs_im1 = q.cs_im1;
-    const bool in_seed = q.in_seed;
+    const bool in_seed = q.in_seed, tm = q.tm, ctm = q.ctm;
     uint32_t ck[4], cl[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) { ck[c] = q.ck[c]; cl[c] = q.cl[c]; }
@@ -373,7 +415,7 @@ PS_HD void nt_tail(const BtHot &h, NLane &L, LaneStats &st, BtMem &m, const NtSt
         if (s > 3) return;
         const uint32_t ok = sel4(ck, s), ol = sel4(cl, s);
         if (ok >= ol) return;
-        L.kr = ok + 1u; L.lr = ol; L.wa -= 1u; L.wb = (L.wb & ~NW_C_MASK) | ((uint32_t)s << 6);     // --i; the rest of the entry stands
+        L.kr = ctm ? (L.kr << 2) | (uint32_t)s : ok + 1u; L.lr = ctm ? ol - ok : ol; L.wa -= 1u; L.wb = (L.wb & ~NW_C_MASK) | ((uint32_t)s << 6);     // --i; the rest of the entry stands
         L.ctl = nl_set_mode(L.ctl, i == 0 ? M_HIT : M_EXACT);
         return;
     }
@@ -427,7 +469,7 @@ PS_HD void nt_tail(const BtHot &h, NLane &L, LaneStats &st, BtMem &m, const NtSt
         wa_i = wa_keep + pos2 + ((uint32_t)ST_I << 24) + (open ? 1u << 26 : 1u << 29);
     }
     {   // deletion children: open from M, extend from D; the four share score, counts and position (they stay at i+1)
-        const uint32_t occ = plr - pkr + 1u;               // never the root here (from_d)
+        const uint32_t occ = tm ? plr : plr - pkr + 1u;    // never the root here (from_d)
         const bool open = from_m && e_go < h.max_gapo();
         const bool ext = from_d && e_ge < h.max_gape() && ((e_ge + e_go) * h.u_tight() < max_units || occ < (uint32_t)h.max_del_occ());
         const int un = e_un + (open ? h.u_gapo_del() : h.u_gape());
@@ -485,20 +527,20 @@ PS_HD void nt_tail(const BtHot &h, NLane &L, LaneStats &st, BtMem &m, const NtSt
         const uint32_t wb_d = ((wb0 & 0x3fu) + (1u << 3)) | ((uint32_t)sc[1] << 9);
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-            if (g[1 + c]) { Entry16 e; e.k = ck[c] + 1u; e.l = cl[c]; e.a = wa_d; e.b = wb_d | ((uint32_t)c << 6) | NT_NEXT(1 + c); store16(pool + idx[1 + c], e); }
+            if (g[1 + c]) { Entry16 e; e.k = ctm ? (pkr << 2) | (uint32_t)c : ck[c] + 1u; e.l = ctm ? cl[c] - ck[c] : cl[c]; e.a = wa_d; e.b = wb_d | ((uint32_t)c << 6) | NT_NEXT(1 + c); store16(pool + idx[1 + c], e); }
     }
     {
         const uint32_t wa_x = wa_keep + pos2 + (1u << 16), wb_x = wb0 & 0x3fu;
 #pragma unroll
         for (int j = 1; j <= 4; ++j) {
             const uint32_t c = (uint32_t)((s + j) & 3);
-            if (g[4 + j]) { Entry16 e; e.k = xk[j - 1] + 1u; e.l = xl[j - 1]; e.a = wa_x; e.b = wb_x | (c << 6) | ((uint32_t)sc[4 + j] << 9) | NT_NEXT(4 + j); store16(pool + idx[4 + j], e); }
+            if (g[4 + j]) { Entry16 e; e.k = ctm ? (pkr << 2) | c : xk[j - 1] + 1u; e.l = ctm ? xl[j - 1] - xk[j - 1] : xl[j - 1]; e.a = wa_x; e.b = wb_x | (c << 6) | ((uint32_t)sc[4 + j] << 9) | NT_NEXT(4 + j); store16(pool + idx[4 + j], e); }
         }
     }
 #undef NT_NEXT
     L.ctl = nl_set_mode(L.ctl, M_POP);
     if (s < 4 && xk[3] < xl[3]) {      // the match child: parent's score, pushed last => the next pop: it stays in registers
-        L.kr = xk[3] + 1u; L.lr = xl[3]; L.wa = wa_keep + (uint32_t)i; L.wb = (L.wb & ~NW_C_MASK) | ((uint32_t)s << 6);
+        L.kr = ctm ? (pkr << 2) | (uint32_t)s : xk[3] + 1u; L.lr = ctm ? xl[3] - xk[3] : xl[3]; L.wa = wa_keep + (uint32_t)i; L.wb = (L.wb & ~NW_C_MASK) | ((uint32_t)s << 6);
         L.ctl |= NL_HAVE_CUR;
     }
     L.n_phantom += phantom;

@@ -45,6 +45,8 @@ struct IndexView {
     bwtint L2[5];
     uint32_t n_blocks, n_sa;
     int sa_intv;
+    const uint32_t *jump;     // child intervals of every string shorter than jump_levels symbols (ps_core.h, "jump table"); derived data, never on disk
+    int jump_levels;          // 0: none
 };
 
 // ---- cost model for one read length (host fills, kernels read) ----------

@@ -13,7 +13,7 @@
 using namespace ps;
 
 struct SimIndex {
-    std::vector<OccBlock> blocks; std::vector<uint32_t> sa; std::vector<uint8_t> pac;
+    std::vector<OccBlock> blocks; std::vector<uint32_t> sa; std::vector<uint8_t> pac, jump_raw;
     IndexView v;
 };
 
@@ -44,6 +44,31 @@ void *hs_index_new(const uint8_t *bwt_syms, uint64_t n, uint64_t primary, const 
     return s;
 }
 void hs_index_free(void *p) { delete (SimIndex *)p; }
+
+// the jump table of the index (ps_core.h), filled by the product's own slot function, level after level; levels < 0: as many
+// as the product would take for this text; 0: none.  Returns the number of levels.
+int hs_index_jump(void *p, int levels)
+{
+    SimIndex *s = (SimIndex *)p;
+    if (levels < 0) levels = jump_levels_for(s->v.seq_len);
+    if (levels > 12) levels = 12;                          // host memory
+    s->v.jump = nullptr; s->v.jump_levels = 0;
+    if (levels == 0) return 0;
+    BtArgs a; memset(&a, 0, sizeof a); a.ix = s->v;
+    BtHot h; (void)bt_hot_make(a, h);
+    s->jump_raw.assign(jump_words(levels) * 4 + 16, 0);
+    uint32_t *t = reinterpret_cast<uint32_t *>((reinterpret_cast<uintptr_t>(s->jump_raw.data()) + 15) & ~(uintptr_t)15);
+    for (int d = 0; d < levels; ++d)
+        for (uint32_t x = 0; x < (1u << (2 * d)); ++x) jump_fill_slot(h, t, s->v.seq_len, d, x);
+    s->v.jump = t; s->v.jump_levels = levels;
+    return levels;
+}
+// a slot of it: the eight words of string `sidx` of level d
+void hs_jump_slot(void *p, int d, uint32_t sidx, uint32_t out[8])
+{
+    SimIndex *s = (SimIndex *)p;
+    memcpy(out, s->v.jump + (size_t)(jump_level_off(d) + sidx) * PS_JUMP_SLOT_WORDS, 32);
+}
 
 uint32_t hs_occ(void *p, int64_t k, int c) // Occ(k,c) through the block code, k in [-1, n]
 {

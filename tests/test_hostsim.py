@@ -33,6 +33,8 @@ def hs():
     H.hs_model_stock.argtypes = [C.c_char_p, C.c_int, C.c_void_p]
     H.hs_model_profile.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int, C.c_void_p]
     H.hs_aln.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 7
+    H.hs_index_jump.argtypes = [C.c_void_p, C.c_int]
+    H.hs_jump_slot.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p]
     H.hs_banded.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_int]
     assert H.hs_sizeof_alnrec() == ALNREC.itemsize
     return H
@@ -43,8 +45,57 @@ def sim_index(hs, example):
     ix = example["orc_index"]
     bw, sa, pac = ix.bwt_syms(), ix.sa_samples(), ix.pac()
     h = hs.hs_index_new(bw.ctypes.data, ix.seq_len, ix.primary, sa.ctypes.data, sa.size, 32, pac.ctypes.data, ix.l_pac)
+    assert hs.hs_index_jump(h, -1) >= 5                     # with the jump table, as deep as the product takes it for this text
     yield h
     hs.hs_index_free(h)
+
+
+@pytest.fixture(scope="module")
+def sim_index_plain(hs, example):
+    """the same index without a jump table: every step through the Occ blocks (what the counting kernel and the wide tier do)"""
+    ix = example["orc_index"]
+    bw, sa, pac = ix.bwt_syms(), ix.sa_samples(), ix.pac()
+    h = hs.hs_index_new(bw.ctypes.data, ix.seq_len, ix.primary, sa.ctypes.data, sa.size, 32, pac.ctypes.data, ix.l_pac)
+    yield h
+    hs.hs_index_free(h)
+
+
+def test_jump_table_slots(hs, sim_index, example):
+    """a slot holds Occ(k-1, .) and Occ(l, .) of its string's interval (the string's symbols in the order the backward search
+    consumes them), all zero where the string does not occur -- against a plain backward search with the oracle's Occ"""
+    ix = example["orc_index"]
+    L2 = [int(x) for x in ix.L2]
+    levels = hs.hs_index_jump(sim_index, 11)                # deeper than the text warrants: strings that do not occur
+    rng = np.random.default_rng(5)
+    out = np.zeros(8, dtype=np.uint32)
+    seen_empty = 0
+    for j in range(600):
+        d = int(rng.integers(0, levels)) if j < 300 else levels - 1
+        syms = [int(x) for x in rng.integers(0, 4, d)]
+        k, l = 0, ix.seq_len
+        for c in syms:
+            k, l = L2[c] + ix.occ(k - 1, c) + 1, L2[c] + ix.occ(l, c)
+            if k > l:
+                break
+        hs.hs_jump_slot(sim_index, d, _pad(syms), out.ctypes.data)
+        if k > l:
+            seen_empty += 1
+            assert not out.any()
+        else:
+            exp = []
+            for c in range(4):
+                exp += [ix.occ(k - 1, c), ix.occ(l, c)]
+            assert out.tolist() == exp, (d, syms)
+    assert seen_empty > 0
+    hs.hs_index_jump(sim_index, -1)
+
+
+def _pad(syms):
+    """index of the whole string (the search above stops at the first empty prefix: every extension of it is empty too)"""
+    v = 0
+    for c in syms:
+        v = v * 4 + c
+    return v
 
 
 def test_occ_blocks_and_sa_walk(hs, sim_index, example):
@@ -116,6 +167,29 @@ def test_lane_reuse_and_few_lanes(hs, sim_index, example):
     model = (C.c_uint8 * hs.hs_sizeof_model())()
     assert hs.hs_model_stock(b"0.04", 50, model) == 0
     _compare(hs, sim_index, example["orc_index"], orc.stock_opt("0.04"), model, sim["codes"], n_lanes=3)
+
+
+@pytest.mark.parametrize("n_arg,L", [("0.04", 50), ("2", 32), ("0.04", 75)])
+def test_lane_machine_without_jump_table(hs, sim_index_plain, example, n_arg, L):
+    sim = S.simulate_reads(example["genome"], 300, L, seed=29 + L, indel_scale=40, n_frac=0.002)
+    model = (C.c_uint8 * hs.hs_sizeof_model())()
+    assert hs.hs_model_stock(n_arg.encode(), L, model) == 0
+    _compare(hs, sim_index_plain, example["orc_index"], orc.stock_opt(n_arg), model, sim["codes"])
+
+
+@pytest.mark.parametrize("L", [6, 8, 11])
+def test_hits_inside_the_jump_table_levels(hs, sim_index, example, L):
+    """reads shorter than the table is deep end their search on an entry that carries (string index, width): the hit takes the
+    interval back out of the parent's slot"""
+    levels = hs.hs_index_jump(sim_index, 12)
+    try:
+        assert levels == 12
+        sim = S.simulate_reads(example["genome"], 300, L, seed=31 + L, indel_scale=40)
+        model = (C.c_uint8 * hs.hs_sizeof_model())()
+        assert hs.hs_model_stock(b"1", L, model) == 0
+        _compare(hs, sim_index, example["orc_index"], orc.stock_opt("1"), model, sim["codes"])
+    finally:
+        hs.hs_index_jump(sim_index, -1)
 
 
 def test_wide_stack_variant(hs, sim_index, example):
