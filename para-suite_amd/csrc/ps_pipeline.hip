@@ -657,6 +657,37 @@ struct PostArgs {
     int budget, profile, unit; const uint8_t *logn;     // MAPQ rule inputs; logn[n] = (int)(4.343 ln n + .5)
     RefineItem *items; int32_t *item_g; unsigned int *n_items;
 };
+// ---- the two samse rules every finished hit goes through, ONE copy for the device kernel and for the host-finished subset ----
+// text position of an SA row -> forward coordinate of the alignment's first base and its strand (upstream bwa_sa2pos /
+// bwa_cal_pac_pos_core); -1: the alignment spans the forward/reverse junction
+__host__ __device__ inline long long rule_to_forward(long long pos_t, long long l_pac, int ref_len, int &strand)
+{
+    long long pos_f = pos_t;
+    strand = 0;
+    if (pos_f < l_pac && l_pac < pos_f + ref_len) return -1;
+    const bool is_rev = pos_f >= l_pac;
+    if (is_rev) pos_f = 2 * l_pac - 1 - pos_f;
+    strand = !is_rev;
+    if (is_rev) pos_f = pos_f + 1 < ref_len ? 0 : pos_f - ref_len + 1;
+    return pos_f;
+}
+// upstream bwa_approx_mapQ with the budget rule of the cost model in use; logn[n] = (int)(4.343 ln n + .5), n < 256
+__host__ __device__ inline int rule_mapq(int c1, int c2, int n_mm, int score, int budget, bool profile, int unit, const uint8_t *logn)
+{
+    if (c1 == 0) return 23;
+    if (c1 > 1) return 0;
+    if (!profile) { if (n_mm == budget) return 25; }
+    else if (budget * unit - score < unit) return 25;
+    if (c2 == 0) return 37;
+    const int lg = logn[c2 >= 255 ? 255 : c2];
+    return 23 < lg ? 0 : 23 - lg;
+}
+static void mapq_logn_table(uint8_t logn[256])
+{
+    logn[0] = 0;
+    for (int n = 1; n < 256; ++n) logn[n] = (uint8_t)(int)(4.343 * std::log((double)n) + 0.5);
+}
+
 // text position -> forward coordinate + strand, MAPQ; gapped hits are queued for the banded-DP kernel
 __global__ void k_post(PostArgs a)
 {
@@ -665,23 +696,10 @@ __global__ void k_post(PostArgs a)
         FinRec f; f.pos = -1; f.strand = 0; f.mapq = 0; f.type = 0; f.pad[0] = f.pad[1] = f.pad[2] = f.pad[3] = f.pad[4] = 0;
         const SelRec s = a.sel[g];
         if (a.cls[g] == 1 && s.type != 0) {
-            long long pos_f = (long long)a.pos[g];
             const int ref_len = (a.lens ? a.lens[r] : a.len) + s.ref_shift;
-            int strand = 0; long long p = -1;
-            if (!(pos_f < a.l_pac && a.l_pac < pos_f + ref_len)) {
-                const bool is_rev = pos_f >= a.l_pac;
-                if (is_rev) pos_f = 2 * a.l_pac - 1 - pos_f;
-                strand = !is_rev;
-                if (is_rev) pos_f = pos_f + 1 < ref_len ? 0 : pos_f - ref_len + 1;
-                p = pos_f;
-            }
-            int mq;
-            if (s.c1 == 0) mq = 23;
-            else if (s.c1 > 1) mq = 0;
-            else if (!a.profile && s.n_mm == a.budget) mq = 25;
-            else if (a.profile && a.budget * a.unit - (int)s.score < a.unit) mq = 25;
-            else if (s.c2 == 0) mq = 37;
-            else { const int nn = s.c2 >= 255 ? 255 : s.c2; const int lg = a.logn[nn]; mq = 23 < lg ? 0 : 23 - lg; }
+            int strand = 0;
+            const long long p = rule_to_forward((long long)a.pos[g], a.l_pac, ref_len, strand);
+            const int mq = rule_mapq(s.c1, s.c2, s.n_mm, (int)s.score, a.budget, a.profile != 0, a.unit, a.logn);
             f.pos = p; f.strand = (uint8_t)strand; f.mapq = (uint8_t)mq; f.type = p < 0 ? 0 : s.type;
             if (f.type != 0 && s.n_gapo) {
                 const unsigned int q = atomicAdd(a.n_items, 1u);
@@ -993,33 +1011,6 @@ void batch_select_easy(Batch &b, int threads)
 }
 
 // ------------------------------------------------- locate / MAPQ / gapped DP ----
-static int mapq_logn(int n) { return (int)(4.343 * std::log((double)n) + 0.5); }
-
-static int approx_mapq(const Hit &h, const Options &o, int len)
-{
-    const int budget = budget_diffs(o, len);
-    if (h.c1 == 0) return 23;
-    if (h.c1 > 1) return 0;
-    if (!o.profile) { if (h.n_mm == budget) return 25; }
-    else if (budget * o.unit - h.score < o.unit) return 25;
-    if (h.c2 == 0) return 37;
-    const int n = h.c2 >= 255 ? 255 : h.c2;
-    return 23 < mapq_logn(n) ? 0 : 23 - mapq_logn(n);
-}
-
-// text position of an SA row -> forward coordinate of the alignment's first base and its strand
-static int64_t to_forward(bwtint pos_t, int64_t l_pac, int ref_len, int &strand)
-{
-    int64_t pos_f = (int64_t)pos_t;
-    strand = 0;
-    if (pos_f < l_pac && l_pac < pos_f + ref_len) return -1;       // spans the forward/reverse junction
-    const bool is_rev = pos_f >= l_pac;
-    if (is_rev) pos_f = 2 * l_pac - 1 - pos_f;
-    strand = !is_rev;
-    if (is_rev) pos_f = pos_f + 1 < ref_len ? 0 : pos_f - ref_len + 1;
-    return pos_f;
-}
-
 static int fix_cigar(uint32_t *cigar, int n, int64_t &rb)
 {
     if (n <= 0) return 0;
@@ -1058,8 +1049,8 @@ void batch_locate(Batch &b)
     auto t0 = Clock::now();
     // ---- device-finished reads: SA walk, strand / MAPQ, queue of gapped hits ----
     { EvTimer t(s); launch_sa2pos(ctx->ix.view, b.d_rows.p, b.d_pos.p, (int)N, b.d_stats.p + 2, s); PS_HIP(hipGetLastError()); b.tm.ms_sa2pos += t.stop(); }
-    uint8_t logn[256]; logn[0] = 0;
-    for (int n = 1; n < 256; ++n) logn[n] = (uint8_t)mapq_logn(n);
+    uint8_t logn[256];
+    mapq_logn_table(logn);
     uint8_t *d_logn = wk->ws_get<uint8_t>("logn", 256);
     PS_HIP(hipMemcpyAsync(d_logn, logn, 256, hipMemcpyHostToDevice, s));
     b.dev_cigars.clear();
@@ -1129,16 +1120,16 @@ void batch_locate(Batch &b)
                     const int len = b.rs.len[sr.g], bi = b.read_bin[sr.g];
                     if (h.type != 0) {
                         int strand = 0;
-                        h.pos = to_forward(pos[q], l_pac, len + h.ref_shift, strand);
+                        h.pos = rule_to_forward((long long)pos[q], l_pac, len + h.ref_shift, strand);
                         h.strand = strand;
-                        h.mapq = approx_mapq(h, ctx->opt, len);
+                        h.mapq = rule_mapq(h.c1, h.c2, h.n_mm, h.score, budget_diffs(ctx->opt, len), ctx->opt.profile, ctx->opt.unit, logn);
                         if (h.pos < 0) h.type = 0;
                     }
                     int kept = 0;
                     for (int j = 0; j < h.n_multi; ++j) {
                         Multi &m = b.multis[h.multi_begin + j];
                         int strand = 0;
-                        m.pos = to_forward(pos[M + h.multi_begin + j], l_pac, len + m.ref_shift, strand);
+                        m.pos = rule_to_forward((long long)pos[M + h.multi_begin + j], l_pac, len + m.ref_shift, strand);
                         m.strand = strand;
                         if (m.pos != h.pos && m.pos >= 0) b.multis[h.multi_begin + kept++] = m;
                     }
