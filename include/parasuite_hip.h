@@ -135,6 +135,14 @@ int     ps_bam_index(const char *bam, int threads);
  * out_prefix NULL or "": the mapping file's name, as in the Java.  A read longer than max_read_len is an error (the
  * Java's arrays would overflow). */
 int     ps_error_profile(const char *mapping_sam_or_bam, const char *ref_fa, int max_read_len, const char *out_prefix);
+/* The first pass and its error profile in one call -- "fed directly from alignment results" (SURVEY.md §8f rank 4): ps_map, and
+ * while the SAM is written the same records, straight from memory, go through the counting kernel: the alignments with
+ * MAPQ >= min_mapq, i.e. what the pass's filtered BAM holds (samtools view -q, PARAsuiteMapping.java:124-133 /
+ * BWAMapping.java) and ErrorProfiling would read back (Main.java:327-334).  Writes <profile_prefix>.errorprofile and
+ * .indelprofile, the same bytes as ps_error_profile on that filtered file.  No BAM round trip between the passes. */
+int     ps_map_profiled(int threads, const char *mm, const char *error_profile, const char *indel_profile,
+                        const char *ref_fa, const char *reads_fq, const char *out_sam,
+                        int min_mapq, int max_read_len, const char *profile_prefix);
 
 #ifdef __cplusplus
 }

@@ -19,6 +19,11 @@ public class NativePARAsuiteMapping extends Mapping {
     private static native int nativeIndex(String reference);
     private static native int nativeMap(int threads, String mm, String errorProfile, String indelProfile,
                                         String reference, String input, String outSam);
+    /** first pass + the error profile of its alignments with MAPQ >= minMapq in one call (instead of Main.java:288-334) */
+    public static native int nativeMapProfiled(int threads, String mm, String reference, String input, String outSam,
+                                               int minMapq, int maxReadLength, String profilePrefix);
+    /** ErrorProfiling.inferErrorProfile(false, false) on an existing SAM / BAM file (Main.java:327-334) */
+    public static native int nativeErrorProfile(String mapping, String reference, int maxReadLength, String outPrefix);
     private static native String nativeLastError();
 
     /* errorProfileFilename == null: the stock first pass (BWAMapping.java:51-75, `bwa aln -n mm`) */

@@ -26,6 +26,26 @@ JNIEXPORT jint JNICALL Java_mapping_NativePARAsuiteMapping_nativeMap(JNIEnv *e, 
     return rc;
 }
 
+/* the first pass together with the ErrorProfiling step behind it (Main.java:288-334): ps_map_profiled */
+JNIEXPORT jint JNICALL Java_mapping_NativePARAsuiteMapping_nativeMapProfiled(JNIEnv *e, jclass k, jint threads, jstring mm,
+        jstring ref, jstring in, jstring out, jint minMapq, jint maxReadLength, jstring profilePrefix)
+{
+    const char *a = str(e, mm), *d = str(e, ref), *f = str(e, in), *g = str(e, out), *p = str(e, profilePrefix);
+    jint rc = ps_map_profiled(threads, a, NULL, NULL, d, f, g, minMapq, maxReadLength, p);
+    rel(e, mm, a); rel(e, ref, d); rel(e, in, f); rel(e, out, g); rel(e, profilePrefix, p);
+    return rc;
+}
+
+/* ErrorProfiling.inferErrorProfile on an existing SAM / BAM file (Main.java:327-334): ps_error_profile */
+JNIEXPORT jint JNICALL Java_mapping_NativePARAsuiteMapping_nativeErrorProfile(JNIEnv *e, jclass k, jstring mapping, jstring ref,
+        jint maxReadLength, jstring prefix)
+{
+    const char *a = str(e, mapping), *b = str(e, ref), *c = str(e, prefix);
+    jint rc = ps_error_profile(a, b, maxReadLength, c);
+    rel(e, mapping, a); rel(e, ref, b); rel(e, prefix, c);
+    return rc;
+}
+
 JNIEXPORT jstring JNICALL Java_mapping_NativePARAsuiteMapping_nativeLastError(JNIEnv *e, jclass k)
 {
     return (*e)->NewStringUTF(e, ps_last_error());

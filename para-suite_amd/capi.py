@@ -44,7 +44,7 @@ EXPORTS = ["ps_version", "ps_last_error", "ps_index", "ps_map", "ps_ctx_open", "
            "ps_ctx_blob", "ps_ctx_meta", "ps_ctx_from_blobs", "ps_ctx_fetch", "ps_ctx_export_blob", "ps_ctx_sa_lookup", "ps_sam_to_bam", "ps_bam_view", "ps_bam_sort", "ps_bam_index", "ps_batch_from_fastq",
            "ps_batch_from_codes", "ps_batch_free", "ps_batch_n", "ps_batch_search", "ps_batch_select_hard",
            "ps_batch_select_easy", "ps_batch_locate", "ps_batch_run", "ps_batch_write_sam", "ps_batch_n_aln",
-           "ps_batch_alns", "ps_batch_hits", "ps_batch_timing", "ps_batch_kstats", "ps_ctx_read_iters", "ps_parse_check", "ps_error_profile"]
+           "ps_batch_alns", "ps_batch_hits", "ps_batch_timing", "ps_batch_kstats", "ps_ctx_read_iters", "ps_parse_check", "ps_error_profile", "ps_map_profiled"]
 
 _LIB = None
 
@@ -328,6 +328,14 @@ def ps_error_profile(mapping, ref_fa, max_read_len=101, out_prefix=None):
     """<out_prefix>.errorprofile / .indelprofile from the records of a SAM or BAM file (counted on the GPU)"""
     L = lib(); L.ps_error_profile.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_char_p]
     _chk(L.ps_error_profile(mapping.encode(), ref_fa.encode(), int(max_read_len), out_prefix.encode() if out_prefix else None))
+
+
+def ps_map_profiled(threads, mm, error_profile, indel_profile, ref_fa, reads, out_sam, min_mapq, max_read_len, profile_prefix):
+    """ps_map + <profile_prefix>.errorprofile / .indelprofile of its alignments with MAPQ >= min_mapq, counted from memory"""
+    enc = lambda v: v.encode() if v else None
+    L = lib(); L.ps_map_profiled.argtypes = [C.c_int] + [C.c_char_p] * 6 + [C.c_int, C.c_int, C.c_char_p]
+    _chk(L.ps_map_profiled(int(threads), enc(str(mm)), enc(error_profile), enc(indel_profile), enc(ref_fa), enc(reads), enc(out_sam),
+                           int(min_mapq), int(max_read_len), enc(profile_prefix)))
 
 
 def ps_index(ref_fa):

@@ -336,8 +336,11 @@ int ps_batch_kstats(ps_batch *b, int which, ps_kstats *o)
 // input order (only the reads whose draw count is data dependent sit on that chain), so the SAM does not depend on the cut,
 // on the number of workers or on the number of devices.  A finished piece gives its device memory back at once and at most
 // a few finished pieces wait for the writer: memory does not grow with the input.
-int ps_map(int threads, const char *mm, const char *error_profile, const char *indel_profile,
-           const char *ref_fa, const char *fastq, const char *out_sam)
+namespace {
+struct ProfileSink { int min_mapq = 0, max_len = 0; std::string prefix; };    // ps_map_profiled: the first pass also counts its error profile
+}
+static int map_core(int threads, const char *mm, const char *error_profile, const char *indel_profile,
+                    const char *ref_fa, const char *fastq, const char *out_sam, const ProfileSink *sink)
 {
     PS_TRY
         const bool verbose = std::getenv("PS_VERBOSE") != nullptr;
@@ -405,7 +408,7 @@ int ps_map(int threads, const char *mm, const char *error_profile, const char *i
         const size_t done_cap = (size_t)n_workers + 2;   // finished pieces that may wait for the writer
         std::vector<int> index_state((size_t)G, 0);      // 0 not there, 1 resident
         auto fail_all = [&](const std::string &m) { { std::lock_guard<std::mutex> l(mu); if (!failed) { failed = true; msg = m; } } cv.notify_all(); parsed.abort(); };
-        double t_parse = 0, t_write = 0, t_release = 0, t_index = 0, t_index_all = 0; std::vector<double> t_gpu((size_t)n_workers, 0.0);
+        double t_parse = 0, t_write = 0, t_release = 0, t_index = 0, t_index_all = 0, t_profile = 0; std::vector<double> t_gpu((size_t)n_workers, 0.0);
         int64_t n_reads = 0, n_pieces = 0;
         // ---- parser (starts at once)
         std::thread parser([&]() {
@@ -423,6 +426,7 @@ int ps_map(int threads, const char *mm, const char *error_profile, const char *i
         std::thread writer([&]() {
             try {
                 bool first = true;
+                std::unique_ptr<ProfileAccum> accum;                   // on the first device, whose index is resident before any piece is finished
                 for (;;) {
                     std::unique_ptr<Batch> b;
                     {
@@ -436,6 +440,14 @@ int ps_map(int threads, const char *mm, const char *error_profile, const char *i
                     const auto t0 = std::chrono::steady_clock::now();
                     batch_write_sam(*b, out_sam, first, "@PG\tID:parasuite-hip\tPN:parasuite-hip\tVN:0.1", nthr, !first);
                     t_write += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                    if (sink) {                                        // the same records, straight from memory, into the profile histograms
+                        const auto tp = std::chrono::steady_clock::now();
+                        if (!accum) accum.reset(new ProfileAccum(xs[0]->c.device, xs[0]->c.ix, sink->max_len));
+                        ProfRecords pr;
+                        batch_profile_records(*b, sink->min_mapq, nthr, pr);
+                        accum->add(pr);
+                        t_profile += std::chrono::duration<double>(std::chrono::steady_clock::now() - tp).count();
+                    }
                     first = false;
                     { std::lock_guard<std::mutex> l(mu); ++write_next; }
                     cv.notify_all();
@@ -447,6 +459,13 @@ int ps_map(int threads, const char *mm, const char *error_profile, const char *i
                     FILE *f = std::fopen(out_sam, "wb");
                     if (!f) throw Error(std::string("cannot write ") + out_sam);
                     std::fclose(f);
+                }
+                if (sink) {
+                    ProfileCounts pc;
+                    if (accum) accum->finish(pc);
+                    else { pc.max_len = sink->max_len; pc.conv.assign((size_t)sink->max_len * 16, 0); pc.ins.assign((size_t)sink->max_len, 0); pc.del.assign((size_t)sink->max_len, 0); }
+                    error_profile_write(pc, sink->prefix);
+                    accum.reset();                                      // before the contexts (and their devices' memory) go
                 }
             } catch (const std::exception &e) { fail_all(e.what()); }
         });
@@ -528,11 +547,27 @@ int ps_map(int threads, const char *mm, const char *error_profile, const char *i
         if (verbose) {
             double busy = 0; for (double v : t_gpu) busy += v;
             std::fprintf(stderr, "[parasuite-hip] ps_map: %lld reads in %lld piece(s) of <= %.0f MB, %d device(s) x %d worker(s), %.3f s; index resident after %.3f s (all devices %.3f s), "
-                                 "parser done after %.3f s, GPU stages busy %.3f s (summed over workers) and done after %.3f s, SAM writer busy %.3f s (+ %.3f s releasing pieces) and done after %.3f s, contexts closed after %.3f s\n", (long long)n_reads, (long long)n_pieces, chunk_bytes / 1048576.0,
-                                 G, dev_workers[0], since(), t_index, t_index_all, t_parse, busy, t_workers, t_write, t_release, t_written, t_closed);
+                                 "parser done after %.3f s, GPU stages busy %.3f s (summed over workers) and done after %.3f s, SAM writer busy %.3f s (+ %.3f s releasing pieces, %.3f s error profile) and done after %.3f s, contexts closed after %.3f s\n", (long long)n_reads, (long long)n_pieces, chunk_bytes / 1048576.0,
+                                 G, dev_workers[0], since(), t_index, t_index_all, t_parse, busy, t_workers, t_write, t_release, t_profile, t_written, t_closed);
         }
         return 0;
     PS_CATCH_INT
+}
+
+int ps_map(int threads, const char *mm, const char *error_profile, const char *indel_profile,
+           const char *ref_fa, const char *fastq, const char *out_sam)
+{
+    return map_core(threads, mm, error_profile, indel_profile, ref_fa, fastq, out_sam, nullptr);
+}
+// ps_map + the error profile of its own alignments (those with MAPQ >= min_mapq: what the filtered BAM of the pass would
+// hold), counted from the records in memory while the SAM is being written: <profile_prefix>.errorprofile / .indelprofile
+int ps_map_profiled(int threads, const char *mm, const char *error_profile, const char *indel_profile,
+                    const char *ref_fa, const char *fastq, const char *out_sam, int min_mapq, int max_read_len, const char *profile_prefix)
+{
+    if (!profile_prefix || !profile_prefix[0]) return fail("ps_map_profiled: no output prefix for the profile files");
+    if (max_read_len < 1 || max_read_len > 4096) return fail("error profile: maximum read length out of range");
+    ProfileSink sink; sink.min_mapq = min_mapq; sink.max_len = max_read_len; sink.prefix = profile_prefix;
+    return map_core(threads, mm, error_profile, indel_profile, ref_fa, fastq, out_sam, &sink);
 }
 
 // host-only: parse reads the way ps_map does (whole file on `threads` threads, or streamed in windows of chunk_bytes) and

@@ -86,6 +86,24 @@ struct ProfileCounts {                 // raw counts, read orientation; [pos][re
     std::vector<unsigned long long> conv, ins, del;     // conv: max_len*16; ins/del: per alignment column (forward strand), max_len
     unsigned long long n_records = 0, n_processed = 0, n_unmapped = 0, n_duplicate = 0, n_start_zero = 0, n_indel_reads = 0, n_skipped = 0;
 };
+// alignment records as the counting kernel takes them (BAM conventions: CIGAR words len<<4|op with MIDNSHP=X, bases as nibbles
+// =ACMGRSVTWYHKDBN in the orientation of the SAM record); gpos = start on the packed forward strand, < 0: not counted
+struct ProfRecords {
+    std::vector<int64_t> gpos; std::vector<int32_t> l_seq; std::vector<uint32_t> flag, cig_off, n_cig, cigar;
+    std::vector<uint64_t> seq_off; std::vector<uint8_t> seq;
+    size_t n() const { return gpos.size(); }
+};
+// device-side totals that several batches of records add to (the fused first pass adds one batch per piece of the input)
+struct Index;
+class ProfileAccum {
+public:
+    ProfileAccum(int device, const Index &ix /* pac and holes; resident on `device` */, int max_len);
+    ~ProfileAccum();
+    void add(const ProfRecords &r);
+    void finish(ProfileCounts &out);          // conv / ins / del and the kernel's counters; the caller fills the record statistics
+private:
+    struct Impl; Impl *p;
+};
 void error_profile_count(const char *mapping_sam_or_bam, const char *ref_prefix, int max_len, int device, int threads, ProfileCounts &out);
 void error_profile_write(const ProfileCounts &c, const std::string &out_prefix);    // <out_prefix>.errorprofile / .indelprofile
 std::string java_double_to_string(double v);                                        // java.lang.Double.toString

@@ -146,5 +146,8 @@ void batch_select_hard(Batch &b, uint64_t draws_before, uint64_t *draws_after);
 void batch_select_easy(Batch &b, int threads);
 void batch_locate(Batch &b);                                    // SA walk kernel, strand / MAPQ, banded DP of gapped hits
 void batch_write_sam(Batch &b, const char *path, bool header, const char *pg_line, int threads, bool append = false);
+// the located hits with MAPQ >= min_mapq as records for the error-profile kernel (what the MAPQ-filtered BAM of the first pass holds:
+// PARAsuiteMapping.java:124-133 -> ErrorProfiling.java:145-172), appended to `out`; host memory only
+void batch_profile_records(const Batch &b, int min_mapq, int threads, ProfRecords &out);
 
 }  // namespace ps

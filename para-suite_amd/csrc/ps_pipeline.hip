@@ -1320,6 +1320,61 @@ static void sam_line(const Batch &b, int64_t g, std::string &o)
     o.push_back('\n');
 }
 
+void batch_profile_records(const Batch &b, int min_mapq, int threads, ProfRecords &out)
+{
+    if (!b.located) throw Error("profile records before locate");
+    const ReadSet &rs = b.rs; const RefSeq &ref = b.ctx->ix.ref;
+    const size_t N = (size_t)rs.n;
+    const int nt = par_threads(N, threads);
+    // pass 1: which reads are in the filtered file, and how much they hold
+    std::vector<uint8_t> keep(N, 0);
+    std::vector<size_t> t_rec(nt + 1, 0), t_cig(nt + 1, 0), t_base(nt + 1, 0);
+    par_for(N, threads, [&](size_t g0, size_t g1, int t) {
+        size_t nr = 0, nc = 0, nb = 0;
+        for (size_t g = g0; g < g1; ++g) {
+            Hit h; b.hit_of((int64_t)g, h);
+            if (h.type == 0 || h.mapq < min_mapq) continue;
+            const int len = rs.len[g];
+            int seqid = 0;
+            const int span = (int)ref_span(h.n_cigar, h.cigar, len);
+            ref.cnt_ambi(h.pos, span, &seqid);
+            const Contig &ct = ref.contigs[seqid];
+            if (h.pos + span - ct.offset > ct.len) continue;          // bridges two sequences: the SAM line carries flag 4 (sam_line)
+            keep[g] = 1; ++nr; nc += h.n_cigar ? (size_t)h.n_cigar : 1; nb += (size_t)len + ((size_t)len & 1);
+        }
+        t_rec[t] = nr; t_cig[t] = nc; t_base[t] = nb;
+    });
+    size_t r0 = out.n(), c0 = out.cigar.size(), b0 = out.seq.size() * 2;     // every record starts on a whole byte
+    std::vector<size_t> br(nt + 1), bc(nt + 1), bb(nt + 1);
+    br[0] = r0; bc[0] = c0; bb[0] = b0;
+    for (int t = 0; t < nt; ++t) { br[t + 1] = br[t] + t_rec[t]; bc[t + 1] = bc[t] + t_cig[t]; bb[t + 1] = bb[t] + t_base[t]; }
+    out.gpos.resize(br[nt]); out.l_seq.resize(br[nt]); out.flag.resize(br[nt]); out.cig_off.resize(br[nt]); out.n_cig.resize(br[nt]); out.seq_off.resize(br[nt]);
+    out.cigar.resize(bc[nt]); out.seq.resize(bb[nt] / 2);
+    // pass 2: fill, every thread its own range
+    static const uint8_t NIB[5] = {1, 2, 4, 8, 15}, NIB_RC[5] = {8, 4, 2, 1, 15};
+    par_for(N, threads, [&](size_t g0, size_t g1, int t) {          // the same ranges as in pass 1
+        size_t r = br[t], c = bc[t], bs = bb[t];
+        for (size_t g = g0; g < g1; ++g) {
+            if (!keep[g]) continue;
+            Hit h; b.hit_of((int64_t)g, h);
+            const int len = rs.len[g];
+            const uint8_t *seq = rs.seq.data() + rs.off[g];
+            out.gpos[r] = h.pos; out.l_seq[r] = len; out.flag[r] = h.strand ? 16u : 0u;
+            out.cig_off[r] = (uint32_t)c; out.seq_off[r] = (uint64_t)bs;
+            if (h.n_cigar) { for (int j = 0; j < h.n_cigar; ++j) { const uint32_t op = h.cigar[j] & 0xfu; out.cigar[c++] = (h.cigar[j] & ~0xfu) | (op == 3 ? 4u : op); } out.n_cig[r] = (uint32_t)h.n_cigar; }
+            else { out.cigar[c++] = (uint32_t)len << 4; out.n_cig[r] = 1; }
+            uint8_t *d = out.seq.data() + bs / 2;
+            for (int i = 0; i < len; i += 2) {
+                const uint8_t hi = h.strand ? NIB_RC[seq[len - 1 - i]] : NIB[seq[i]];
+                const uint8_t lo = i + 1 < len ? (h.strand ? NIB_RC[seq[len - 2 - i]] : NIB[seq[i + 1]]) : 0;
+                d[i >> 1] = (uint8_t)(hi << 4 | lo);
+            }
+            bs += (size_t)len + ((size_t)len & 1);
+            ++r;
+        }
+    });
+}
+
 void batch_write_sam(Batch &b, const char *path, bool header, const char *pg_line, int threads, bool append)
 {
     if (!b.located) throw Error("write_sam before locate");

@@ -124,6 +124,69 @@ __global__ void __launch_bounds__(256) k_profile(ProfArgs a)
     if (n_long) atomicAdd(&a.stat[3], n_long);
 }
 
+struct ProfileAccum::Impl {
+    int device, max_len; hipStream_t s = nullptr; const uint8_t *pac;
+    DevBuf<int64_t> d_hoff; DevBuf<int32_t> d_hlen; int n_holes = 0;
+    DevBuf<unsigned long long> d_acc; size_t n_acc = 0;
+};
+ProfileAccum::ProfileAccum(int device, const Index &ix, int max_len) : p(new Impl())
+{
+    if (max_len < 1 || max_len > 4096) { delete p; throw Error("error profile: maximum read length out of range"); }
+    p->device = device; p->max_len = max_len; p->pac = ix.pac.p;
+    try {
+        require_device(device);
+        PS_HIP(hipStreamCreateWithFlags(&p->s, hipStreamNonBlocking));
+        std::vector<int64_t> hoff(ix.ref.holes.size()); std::vector<int32_t> hlen(ix.ref.holes.size());
+        for (size_t h = 0; h < ix.ref.holes.size(); ++h) { hoff[h] = ix.ref.holes[h].offset; hlen[h] = ix.ref.holes[h].len; }
+        p->n_holes = (int)hoff.size();
+        p->d_hoff.alloc(std::max<size_t>(1, hoff.size())); p->d_hlen.alloc(std::max<size_t>(1, hlen.size()));
+        if (!hoff.empty()) { p->d_hoff.upload(hoff.data(), hoff.size(), p->s); p->d_hlen.upload(hlen.data(), hlen.size(), p->s); }
+        p->n_acc = (size_t)max_len * 18 + 4;
+        p->d_acc.alloc(p->n_acc); p->d_acc.zero(p->s);
+        PS_HIP(hipStreamSynchronize(p->s));
+    } catch (...) { if (p->s) (void)hipStreamDestroy(p->s); delete p; throw; }
+}
+ProfileAccum::~ProfileAccum() { if (p->s) (void)hipStreamDestroy(p->s); delete p; }
+void ProfileAccum::add(const ProfRecords &t)
+{
+    const size_t n = t.n();
+    if (!n) return;
+    if (n > 0x7fffffffull) throw Error("error profile: more than 2^31 records in one call");
+    require_device(p->device);
+    hipStream_t s = p->s;
+    std::vector<int32_t> lo(n), hi(n);
+    for (size_t i = 0; i < n; ++i) { const int64_t g = t.gpos[i]; lo[i] = g < 0 ? 0 : (int32_t)(uint32_t)(g & 0xffffffffll); hi[i] = g < 0 ? -1 : (int32_t)(g >> 32); }
+    DevBuf<int32_t> d_lo, d_hi, d_lseq; DevBuf<uint32_t> d_flag, d_coff, d_nc, d_cig; DevBuf<uint64_t> d_soff; DevBuf<uint8_t> d_seq;
+    auto up = [&](auto &d, const auto &v) { d.alloc(std::max<size_t>(1, v.size())); if (!v.empty()) d.upload(v.data(), v.size(), s); };
+    up(d_lo, lo); up(d_hi, hi); up(d_lseq, t.l_seq); up(d_flag, t.flag); up(d_coff, t.cig_off); up(d_nc, t.n_cig); up(d_cig, t.cigar); up(d_soff, t.seq_off); up(d_seq, t.seq);
+    const int max_len = p->max_len;
+    ProfArgs a;
+    a.ref_off_lo = d_lo.p; a.ref_off_hi = d_hi.p; a.l_seq = d_lseq.p; a.flag = d_flag.p; a.cig_off = d_coff.p; a.n_cig = d_nc.p; a.cigar = d_cig.p;
+    a.seq_off = d_soff.p; a.seq = d_seq.p; a.pac = p->pac; a.hole_off = p->d_hoff.p; a.hole_len = p->d_hlen.p; a.n_holes = p->n_holes;
+    a.n_records = (int)n; a.max_len = max_len;
+    a.conv = p->d_acc.p; a.ins = p->d_acc.p + (size_t)max_len * 16; a.del = a.ins + max_len; a.stat = a.del + max_len;
+    const size_t lds = (size_t)max_len * 18 * sizeof(unsigned int);
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_profile), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    int blocks = (int)std::min<size_t>(2048, (n + 255) / 256); if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_profile, dim3(blocks), dim3(256), lds, s, a);
+    PS_HIP(hipGetLastError());
+    PS_HIP(hipStreamSynchronize(s));          // the record arrays above are released on return
+}
+void ProfileAccum::finish(ProfileCounts &out)
+{
+    require_device(p->device);
+    const int max_len = p->max_len;
+    std::vector<unsigned long long> acc(p->n_acc);
+    p->d_acc.download(acc.data(), p->n_acc, p->s);
+    PS_HIP(hipStreamSynchronize(p->s));
+    out.max_len = max_len;
+    out.conv.assign(acc.begin(), acc.begin() + (size_t)max_len * 16);
+    out.ins.assign(acc.begin() + (size_t)max_len * 16, acc.begin() + (size_t)max_len * 17);
+    out.del.assign(acc.begin() + (size_t)max_len * 17, acc.begin() + (size_t)max_len * 18);
+    out.n_processed = acc[(size_t)max_len * 18]; out.n_indel_reads = acc[(size_t)max_len * 18 + 1]; out.n_skipped = acc[(size_t)max_len * 18 + 2];
+    if (acc[(size_t)max_len * 18 + 3]) throw Error("error profile: a read (or its reference span) is longer than the maximum read length given (the reference's arrays would overflow)");
+}
+
 void error_profile_count(const char *mapping, const char *ref_prefix, int max_len, int device, int threads, ProfileCounts &out)
 {
     if (max_len < 1 || max_len > 4096) throw Error("error profile: maximum read length out of range");
@@ -139,46 +202,23 @@ void error_profile_count(const char *mapping, const char *ref_prefix, int max_le
     std::vector<int> ref_to_contig(t.refs.size(), -1);
     for (size_t r = 0; r < t.refs.size(); ++r) { auto it = cid.find(t.refs[r].first); if (it != cid.end()) ref_to_contig[r] = it->second; }
     const size_t n = t.n();
-    out = ProfileCounts(); out.max_len = max_len; out.n_records = n;
-    std::vector<int32_t> lo(n), hi(n);
+    out = ProfileCounts(); out.max_len = max_len;
+    unsigned long long n_unmapped = 0, n_duplicate = 0, n_start_zero = 0;
+    ProfRecords r;
+    r.gpos.assign(n, -1);
     for (size_t i = 0; i < n; ++i) {
-        hi[i] = -1; lo[i] = 0;
-        if (t.flag[i] & 4u) { ++out.n_unmapped; continue; }                       // ErrorProfiling.java:155-158
-        if (t.flag[i] & 1024u) { ++out.n_duplicate; continue; }                   // :159-162
-        if (t.pos[i] < 0) { ++out.n_start_zero; continue; }                       // :163-166 (alignment start 0 = no position)
+        if (t.flag[i] & 4u) { ++n_unmapped; continue; }                       // ErrorProfiling.java:155-158
+        if (t.flag[i] & 1024u) { ++n_duplicate; continue; }                   // :159-162
+        if (t.pos[i] < 0) { ++n_start_zero; continue; }                       // :163-166 (alignment start 0 = no position)
         if (t.ref[i] < 0 || (size_t)t.ref[i] >= ref_to_contig.size() || ref_to_contig[t.ref[i]] < 0) throw Error("error profile: a record names a sequence the reference does not have");
-        const Contig &c = ix.ref.contigs[ref_to_contig[t.ref[i]]];
-        const int64_t g = c.offset + (int64_t)t.pos[i];
-        lo[i] = (int32_t)(uint32_t)(g & 0xffffffffll); hi[i] = (int32_t)(g >> 32);
+        r.gpos[i] = ix.ref.contigs[ref_to_contig[t.ref[i]]].offset + (int64_t)t.pos[i];
     }
-    std::vector<int64_t> hoff(ix.ref.holes.size()); std::vector<int32_t> hlen(ix.ref.holes.size());
-    for (size_t h = 0; h < ix.ref.holes.size(); ++h) { hoff[h] = ix.ref.holes[h].offset; hlen[h] = ix.ref.holes[h].len; }
-    DevBuf<int32_t> d_lo, d_hi, d_lseq, d_hlen; DevBuf<uint32_t> d_flag, d_coff, d_nc, d_cig; DevBuf<uint64_t> d_soff; DevBuf<uint8_t> d_seq; DevBuf<int64_t> d_hoff;
-    DevBuf<unsigned long long> d_acc;
-    auto up = [&](auto &d, const auto &v) { d.alloc(std::max<size_t>(1, v.size())); if (!v.empty()) d.upload(v.data(), v.size(), s); };
-    up(d_lo, lo); up(d_hi, hi); up(d_lseq, t.l_seq); up(d_flag, t.flag); up(d_coff, t.cig_off); up(d_nc, t.n_cig); up(d_cig, t.cigar); up(d_soff, t.seq_off); up(d_seq, t.seq);
-    up(d_hoff, hoff); up(d_hlen, hlen);
-    const size_t n_acc = (size_t)max_len * 18 + 4;
-    d_acc.alloc(n_acc); d_acc.zero(s);
-    ProfArgs a;
-    a.ref_off_lo = d_lo.p; a.ref_off_hi = d_hi.p; a.l_seq = d_lseq.p; a.flag = d_flag.p; a.cig_off = d_coff.p; a.n_cig = d_nc.p; a.cigar = d_cig.p;
-    a.seq_off = d_soff.p; a.seq = d_seq.p; a.pac = ix.pac.p; a.hole_off = d_hoff.p; a.hole_len = d_hlen.p; a.n_holes = (int)hoff.size();
-    a.n_records = (int)n; a.max_len = max_len;
-    a.conv = d_acc.p; a.ins = d_acc.p + (size_t)max_len * 16; a.del = a.ins + max_len; a.stat = a.del + max_len;
-    if (n > 0x7fffffffull) throw Error("error profile: more than 2^31 records in one call");
-    const size_t lds = (size_t)max_len * 18 * sizeof(unsigned int);
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_profile), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    int blocks = (int)std::min<size_t>(2048, (n + 255) / 256); if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_profile, dim3(blocks), dim3(256), lds, s, a);
-    PS_HIP(hipGetLastError());
-    std::vector<unsigned long long> acc(n_acc);
-    d_acc.download(acc.data(), n_acc, s);
-    PS_HIP(hipStreamSynchronize(s));
-    out.conv.assign(acc.begin(), acc.begin() + (size_t)max_len * 16);
-    out.ins.assign(acc.begin() + (size_t)max_len * 16, acc.begin() + (size_t)max_len * 17);
-    out.del.assign(acc.begin() + (size_t)max_len * 17, acc.begin() + (size_t)max_len * 18);
-    out.n_processed = acc[(size_t)max_len * 18]; out.n_indel_reads = acc[(size_t)max_len * 18 + 1]; out.n_skipped = acc[(size_t)max_len * 18 + 2];
-    if (acc[(size_t)max_len * 18 + 3]) throw Error("error profile: a read (or its reference span) is longer than the maximum read length given (the reference's arrays would overflow)");
+    r.l_seq = std::move(t.l_seq); r.flag = std::move(t.flag); r.cig_off = std::move(t.cig_off); r.n_cig = std::move(t.n_cig); r.cigar = std::move(t.cigar);
+    r.seq_off = std::move(t.seq_off); r.seq = std::move(t.seq);
+    ProfileAccum acc(device, ix, max_len);
+    acc.add(r);
+    acc.finish(out);
+    out.n_records = n; out.n_unmapped = n_unmapped; out.n_duplicate = n_duplicate; out.n_start_zero = n_start_zero;
 }
 
 // java.lang.Double.toString: the shortest decimal that reads back as the same double (the JDK 19+ definition; older JDKs

@@ -78,6 +78,20 @@ class BWAMapping(Mapping):
                    capi.ps_map, threads, additionalOptions, None, None, reference, input, outputPrefix + ".sam")
         self.seconds = self.calculatePassedTime()
 
+    def executeMappingWithProfile(self, threads, reference, input, outputPrefix, mappingQualityFilter, additionalOptions, maxReadLength):
+        """the first pass of a --refine run and the ErrorProfiling step behind it (Main.java:288-334) as ONE call: the profile of
+        the alignments with MAPQ >= mappingQualityFilter is counted from memory while the SAM is written (`ps_map_profiled`);
+        returns the two file names Main hands to PARAsuiteMapping (<outputPrefix>.bam.errorprofile / .indelprofile)"""
+        if not os.path.exists(reference + ".bwt"):
+            self._call("bwa index " + reference, capi.ps_index, reference)
+        self.setTimeStart()
+        prefix = outputPrefix + ".bam"                                    # Main.java:335-338: genomicMappingFileName + ".errorprofile"
+        self._call("bwa aln -t %d -n %s %s %s | bwa samse | ErrorProfiling" % (threads, additionalOptions, reference, input),
+                   capi.ps_map_profiled, threads, additionalOptions, None, None, reference, input, outputPrefix + ".sam",
+                   mappingQualityFilter, maxReadLength, prefix)
+        self.seconds = self.calculatePassedTime()
+        return prefix + ".errorprofile", prefix + ".indelprofile"
+
 
 class PARAsuiteMapping(Mapping):
     """refine pass with the error profile: `bwa parasuite -t T -X mm -p EP -g IP` + `bwa samse`

@@ -125,6 +125,20 @@ def test_hip_profile_identical_to_oracle(mid, workdir):
     capi.ps_error_profile(first + ".bam", fa, 101, os.path.join(workdir, "ep_bam"))
     assert open(os.path.join(workdir, "ep_bam.errorprofile"), "rb").read() == exp_e
     assert open(os.path.join(workdir, "ep_bam.indelprofile"), "rb").read() == exp_i
+    # the fused first pass: same SAM, and the profile of the MAPQ-filtered records counted from memory == the profile of the
+    # filtered BAM file (what Main.java:327-334 would hand to ErrorProfiling), also for the oracle reading that file
+    fused = os.path.join(workdir, "ep_fused")
+    fe, fi = mod.mapping.BWAMapping().executeMappingWithProfile(8, fa, fq, fused, 30, "2", 101)
+    assert sam_records(fused + ".sam") == recs
+    capi.ps_sam_to_bam(sam, first + ".q30.bam", 30, True, True, 8)
+    capi.ps_error_profile(first + ".q30.bam", fa, 101, os.path.join(workdir, "ep_q30"))
+    q_e, q_i = open(os.path.join(workdir, "ep_q30.errorprofile"), "rb").read(), open(os.path.join(workdir, "ep_q30.indelprofile"), "rb").read()
+    assert q_e != exp_e                                                  # the filter matters (MAPQ 25 = difference budget used up: those reads carry more errors)
+    assert open(fe, "rb").read() == q_e and open(fi, "rb").read() == q_i
+    mod.mapping.Mapping.filter_sam_mapq(sam, first + ".q30.sam", 30)
+    orc.error_profile(first + ".q30.sam", fa, 101, os.path.join(workdir, "ep_q30_orc"))
+    assert open(os.path.join(workdir, "ep_q30_orc.errorprofile"), "rb").read() == q_e
+    assert open(os.path.join(workdir, "ep_q30_orc.indelprofile"), "rb").read() == q_i
     # a read longer than maxReadLength is an error (the Java's arrays would overflow), not a silent truncation
     with pytest.raises(capi.PsError):
         capi.ps_error_profile(sam, fa, 40, os.path.join(workdir, "ep_short"))
