@@ -355,7 +355,8 @@ bool launch_backtrack(const BtArgs &a_in, const BtArgs *d_args, int n_blocks, in
     // the counting kernel counts the blocks of the plain algorithm (SURVEY.md 8d's figure), the wide tier keeps whole intervals
     // in its entries: both search without the jump table.  PS_JUMP=0: the timed kernel too (A/B measurements)
     const char *ej = std::getenv("PS_JUMP");
-    if (stats || a.wide || (ej && std::atoi(ej) == 0)) { a.ix.jump = nullptr; a.ix.jump_levels = 0; }
+    const bool stats_plain = stats && !std::getenv("PS_STATS_JUMP");     // PS_STATS_JUMP=1: diagnostic runs of the counting / stamps build WITH the table
+    if (stats_plain || a.wide || (ej && std::atoi(ej) == 0)) { a.ix.jump = nullptr; a.ix.jump_levels = 0; }
     BtHot h;
     if (!bt_hot_make(a, h)) return false;       // a model field outside its packed range
     (void)hipMemcpyAsync(const_cast<BtArgs *>(d_args), &a, sizeof(BtArgs), hipMemcpyHostToDevice, s);
