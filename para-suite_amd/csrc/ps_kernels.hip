@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(256) k_backtrack_wide(const BtArgs *__restrict
 
 // The narrow tiers (16-byte stack entries; ps_narrow.h): the same read hand-out, the lane state packed, and a stack that
 // grows inside the launch: a read that outgrows its private slice moves to one of the large slots (wave-cooperative copy).  STATS: per-lane counters for the roofline accounting and the per-read profile -- the timed kernel has none.
-template <bool STATS>
+template <bool STATS, bool NB32>
 __global__ void __launch_bounds__(256, PS_BT_WAVES) k_backtrack_n(const BtArgs *__restrict__ ap, BtHot hk, int lm_stride)
 {
     const BtArgs &a = *ap;      // arguments live in device memory: the cold (non-inlined) paths take their address
@@ -257,7 +257,7 @@ __global__ void __launch_bounds__(256, PS_BT_WAVES) k_backtrack_n(const BtArgs *
                 if (lane == src) { m.pool = dp; L.ctl = nl_set_mode(L.ctl | NL_BIG, M_EXPAND); }
             } else if (lane == src) L.ctl = nl_set_mode(nl_set_status(L.ctl, RS_OVERFLOW_POOL), M_POP);
         }
-        nt_iter<STATS>(a, h, L, st, m, fetch_r, serve_hit, &clk);
+        nt_iter<STATS, NB32>(a, h, L, st, m, fetch_r, serve_hit, &clk);
         if (STATS && a.read_iters) {                           // per-read profile: iterations and stack slots used
             const int now = nl_mode(L.ctl);
             if (mode == M_FETCH && now != M_FETCH && now != M_EXIT) iters0 = st.iters - 1u;
@@ -361,12 +361,13 @@ bool launch_backtrack(const BtArgs &a_in, const BtArgs *d_args, int n_blocks, in
     if (!bt_hot_make(a, h)) return false;       // a model field outside its packed range
     (void)hipMemcpyAsync(const_cast<BtArgs *>(d_args), &a, sizeof(BtArgs), hipMemcpyHostToDevice, s);
     const size_t lds = (size_t)256 * lm_stride;
-    const void *fn = a.wide ? reinterpret_cast<const void *>(k_backtrack_wide)
-                   : stats ? reinterpret_cast<const void *>(k_backtrack_n<true>) : reinterpret_cast<const void *>(k_backtrack_n<false>);
+    const bool nb32 = a.md.n_buckets <= 32;        // one-word bucket bitmap (ps_narrow.h)
+    typedef void (*KernelN)(const BtArgs *, BtHot, int);
+    const KernelN kn = stats ? (nb32 ? k_backtrack_n<true, true> : k_backtrack_n<true, false>) : (nb32 ? k_backtrack_n<false, true> : k_backtrack_n<false, false>);
+    const void *fn = a.wide ? reinterpret_cast<const void *>(k_backtrack_wide) : reinterpret_cast<const void *>(kn);
     if (lds > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (a.wide) hipLaunchKernelGGL(k_backtrack_wide, dim3(n_blocks), dim3(256), lds, s, d_args, h, lm_stride);
-    else if (stats) hipLaunchKernelGGL(k_backtrack_n<true>, dim3(n_blocks), dim3(256), lds, s, d_args, h, lm_stride);
-    else hipLaunchKernelGGL(k_backtrack_n<false>, dim3(n_blocks), dim3(256), lds, s, d_args, h, lm_stride);
+    else hipLaunchKernelGGL(kn, dim3(n_blocks), dim3(256), lds, s, d_args, h, lm_stride);
     return true;
 }
 void launch_sa2pos(const IndexView &ix, const bwtint *rows, bwtint *out, int n, KStats *stats, hipStream_t s)

@@ -310,11 +310,14 @@ PS_HD void nt_push(NLane &L, BtMem &m, uint32_t kr, uint32_t lr, uint32_t wa, ui
     L.bm0 |= bit;
 }
 
-// pop the newest entry of the lowest non-empty bucket into the lane's current-entry registers
+// pop the newest entry of the lowest non-empty bucket into the lane's current-entry registers.  NB32: the cost model has at
+// most 32 score buckets (every default one has): the bitmap of non-empty buckets is handled as ONE word -- the 64-bit shifts,
+// tests and ors of the general form run at a fraction of the 32-bit rate, nine times per expansion
+template <bool NB32>
 PS_HD void nt_pop(NLane &L, BtMem &m)
 {
 #ifdef __HIP_DEVICE_COMPILE__
-    const int b = __ffsll((unsigned long long)L.bm0) - 1;
+    const int b = NB32 ? __ffs((int)(uint32_t)L.bm0) - 1 : __ffsll((unsigned long long)L.bm0) - 1;
 #else
     const int b = __builtin_ctzll(L.bm0);
 #endif
@@ -323,7 +326,7 @@ PS_HD void nt_pop(NLane &L, BtMem &m)
     load16(reinterpret_cast<const Entry16 *>(m.pool) + hd, e);
     const uint32_t next = e.b >> 16;
     L.fh = hd;
-    if (next == PS_NIL16) L.bm0 &= ~(1ull << b); else m.heads16[b] = (uint16_t)next;
+    if (next == PS_NIL16) { if (NB32) L.bm0 = (uint32_t)L.bm0 & ~(1u << b); else L.bm0 &= ~(1ull << b); } else m.heads16[b] = (uint16_t)next;
     L.kr = e.k; L.lr = e.l; L.wa = e.a; L.wb = e.b & 0xffffu;
     L.nsb -= 1u;
 }
@@ -334,7 +337,7 @@ PS_HD void nt_pop(NLane &L, BtMem &m)
 // Three parts, each entered by the whole wave: nt_head (hits, new reads, the pop and its checks; returns M_EXACT /
 // M_EXPAND for the lanes that go on, 0 for the others), nt_step_occ (the memory step), nt_tail (exact extension or
 // expansion and pushes).
-template <bool STATS>
+template <bool STATS, bool NB32>
 PS_HD int nt_head(const BtArgs &a, const BtHot &h, NLane &L, LaneStats &st, BtMem &m, int fetch_r, bool serve_hit)
 {
     int mode = nl_mode(L.ctl);
@@ -362,7 +365,7 @@ PS_HD int nt_head(const BtArgs &a, const BtHot &h, NLane &L, LaneStats &st, BtMe
         }
         if (n_virtual == 0 || n_virtual > (int)h.max_entries || nl_status(L.ctl) != RS_OK) { nt_finish_read(a, L); return 0; }
         if (L.ctl & NL_HAVE_CUR) L.ctl &= ~NL_HAVE_CUR;
-        else { nt_pop(L, m); if (STATS) ++st.pops; }
+        else { nt_pop<NB32>(L, m); if (STATS) ++st.pops; }
         L.ctl = nl_set_mode(L.ctl, M_POP);
         const int score = nw_score(L.wb), i1 = nw_i(L.wa);
         if (score > nl_best_score(L) + h.s_stop()) { nt_finish_read(a, L); return 0; }
@@ -399,7 +402,7 @@ PS_HD void nt_step_occ(const BtHot &h, NLane &L, LaneStats &st, BtMem &m, NtStep
     else nt_occ<STATS>(h, nw_c(L.wb), L.kr, L.lr, q.ck, q.cl, st);
 }
 
-template <bool STATS>
+template <bool STATS, bool NB32>
 PS_HD void nt_tail(const BtHot &h, NLane &L, LaneStats &st, BtMem &m, const NtStep &q, int mode)
 {
     const int len = nl_len(L), i = q.i, s = q.s;
@@ -505,12 +508,18 @@ PS_HD void nt_tail(const BtHot &h, NLane &L, LaneStats &st, BtMem &m, const NtSt
     for (int j = 0; j < 9; ++j) {
         idx[j] = 0; raw[j] = 0;
         if (g[j]) {
-            const unsigned long long bit = 1ull << sc[j];
             idx[j] = nt_slot(L);
             raw[j] = m.heads16[sc[j]];
             m.heads16[sc[j]] = (uint16_t)idx[j];
-            valid |= (L.bm0 & bit) ? 1u << j : 0u;
-            L.bm0 |= bit;
+            if (NB32) {
+                const uint32_t bit = 1u << sc[j], lo = (uint32_t)L.bm0;
+                valid |= (lo & bit) ? 1u << j : 0u;
+                L.bm0 = lo | bit;
+            } else {
+                const unsigned long long bit = 1ull << sc[j];
+                valid |= (L.bm0 & bit) ? 1u << j : 0u;
+                L.bm0 |= bit;
+            }
             if (STATS) ++st.pushes;
         }
     }
@@ -546,11 +555,11 @@ PS_HD void nt_tail(const BtHot &h, NLane &L, LaneStats &st, BtMem &m, const NtSt
     L.n_phantom += phantom;
 }
 
-template <bool STATS>
+template <bool STATS, bool NB32>
 PS_HD void nt_iter(const BtArgs &a, const BtHot &h, NLane &L, LaneStats &st, BtMem &m, int fetch_r, bool serve_hit, NtClock *clk = nullptr)
 {
     PS_USTAMP(clk, 0);                                   // read hand-out, stack moves (the kernel loop), up to here
-    const int mode = nt_head<STATS>(a, h, L, st, m, fetch_r, serve_hit);
+    const int mode = nt_head<STATS, NB32>(a, h, L, st, m, fetch_r, serve_hit);
     PS_USTAMP(clk, 1);                                   // hits, new reads, the pop and its checks
     NtStep q;
     if (mode) nt_step_occ<STATS>(h, L, st, m, q);
@@ -558,7 +567,7 @@ PS_HD void nt_iter(const BtArgs &a, const BtHot &h, NLane &L, LaneStats &st, BtM
     if (STATS && clk && mode) asm volatile("" :: "v"(q.ck[0]), "v"(q.cl[0]), "v"(q.ck[3]), "v"(q.cl[3]));
 #endif
     PS_USTAMP(clk, 2);                                   // the memory step
-    if (mode) nt_tail<STATS>(h, L, st, m, q, mode);
+    if (mode) nt_tail<STATS, NB32>(h, L, st, m, q, mode);
     PS_USTAMP(clk, 3);                                   // exact extension / expansion and pushes
 }
 

@@ -138,6 +138,7 @@ int hs_aln(void *p, const Model *md, int n_reads, int len, const uint8_t *codes,
     std::vector<uint8_t> lm((size_t)n_lanes * lmb);
     std::vector<BtLane> lanes(n_lanes); std::vector<NLane> nlanes(n_lanes); std::vector<LaneStats> nst(n_lanes); std::vector<int> next(n_lanes);
     for (int t = 0; t < n_lanes; ++t) { memset(&lanes[t], 0, sizeof(BtLane)); lanes[t].mode = M_FETCH; nl_init(nlanes[t]); ls_init(nst[t]); next[t] = t; }
+    const bool nb32 = md->n_buckets <= 32 && (n_lanes & 1) == 0;        // as the product chooses; odd lane counts: the general 64-bit form on any model
     BtHot h;
     a.big_cap = wide ? 0 : big_cap;
     if (!bt_hot_make(a, h)) return -2;
@@ -151,7 +152,7 @@ int hs_aln(void *p, const Model *md, int n_reads, int len, const uint8_t *codes,
             if (!wide) {                                     // the narrow tiers: packed lane state (ps_narrow.h)
                 NLane &L = nlanes[t];
                 int mode = nl_mode(L.ctl);
-                if (mode == M_EXIT) { m.pool = priv; m.heads = nullptr; nt_iter<true>(a, h, L, nst[t], m, -1, true); continue; }   // the kernel calls retired lanes too: must be a no-op
+                if (mode == M_EXIT) { m.pool = priv; m.heads = nullptr; if (nb32) nt_iter<true, true>(a, h, L, nst[t], m, -1, true); else nt_iter<true, false>(a, h, L, nst[t], m, -1, true); continue; }   // the kernel calls retired lanes too: must be a no-op
                 if (mode == M_FETCH) { cur_pool[t] = priv; L.ctl &= ~NL_BIG; }      // read done: a large slot goes back, the next read starts on the private slice
                 if (!cur_pool[t]) cur_pool[t] = priv;
                 if (mode == M_GROW) {                        // what the kernel does wave-cooperatively
@@ -165,7 +166,8 @@ int hs_aln(void *p, const Model *md, int n_reads, int len, const uint8_t *codes,
                 m.pool = cur_pool[t]; m.heads = nullptr;
                 int fr = -1;                               // static hand-out here; the kernel deals reads from a queue
                 if (mode == M_FETCH) { fr = next[t] < n_reads ? next[t] : n_reads; next[t] += n_lanes; }
-                nt_iter<true>(a, h, L, nst[t], m, fr, (t & 1) != 0 || (nst[t].iters & 3) == 0);
+                if (nb32) nt_iter<true, true>(a, h, L, nst[t], m, fr, (t & 1) != 0 || (nst[t].iters & 3) == 0);
+                else nt_iter<true, false>(a, h, L, nst[t], m, fr, (t & 1) != 0 || (nst[t].iters & 3) == 0);
                 any = true;
                 continue;
             }
@@ -230,7 +232,7 @@ int hs_unit_rows33(void)
             const uint32_t wa = 17u | (17u << 8) | (3u << 16) | (((uint32_t)ST_D | (2u << 2) | (5u << 5)) << 24), wb = 7u | (6u << 3) | (3u << 6) | (9u << 9);
             nt_push(N, m, (uint32_t)k, (uint32_t)l, wa, wb);
             N.kr = N.lr = N.wa = N.wb = 0;
-            nt_pop(N, m);
+            nt_pop<false>(N, m);
             if (N.kr != (uint32_t)k || N.lr != (uint32_t)l || N.wa != wa || N.wb != wb || nl_n_stack(N) != 0 || N.bm0 != 0) return 1;
             if (nw_i(N.wa) != 17 || nw_ldp(N.wa) != 17 || nw_mm(N.wa) != 3 || nw_state(N.wa) != ST_D || nw_gapo(N.wa) != 2 || nw_gape(N.wa) != 5 ||
                 nw_ins(N.wb) != 7 || nw_del(N.wb) != 6 || nw_c(N.wb) != 3 || nw_score(N.wb) != 9) return 2;
