@@ -203,6 +203,9 @@ def main():
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--penalty", choices=["profile", "stock"], default="profile", help="full workload: PAR-CLIP error-profile costs (bwa parasuite) or stock costs (bwa aln -n 0.04)")
     ap.add_argument("--sub-batches", type=int, default=1, help="2: the batch of a step is mapped as two halves on two lanes (streams) driven by two threads; measured slower than 1 (DESIGN.md section 5)")
+    ap.add_argument("--pipeline", type=int, default=2, help="batches in flight per GPU (1 or 2; 2 needs --sub-batches 1): with 2, consecutive steps alternate between two "
+                    "batches on two streams and the search launch of step k+1 is submitted while step k's still runs, so that it takes the CUs step k's "
+                    "retiring workgroups leave (tools/backfill_probe.py, tools/pipeline_probe.py)")
     ap.add_argument("--e2e", type=int, default=1, help="N=1: also time one ps_map call, FASTQ file -> closed SAM file (the reference's own timer scope)")
     ap.add_argument("--dump-hits", default="", help="directory: every rank saves the per-read hit records of its last step (tests)")
     ap.add_argument("--keep", default="")
@@ -233,6 +236,7 @@ def main():
     threads = args.threads or min(16, max(1, (os.cpu_count() or 8) // max(1, world)))
     log = (lambda *a: print("[bench r%d]" % rank, *a, file=sys.stderr, flush=True))
     S = 2 if args.sub_batches >= 2 else 1
+    PIPE = 2 if (args.pipeline >= 2 and S == 1) else 1        # the context has two lanes of work (stream + workspace)
     do_e2e = bool(args.e2e) and world == 1
 
     # ---------------- data: genome on every rank (same seed), index built on rank 0 ----------------
@@ -289,15 +293,18 @@ def main():
     del contigs
     torch.cuda.empty_cache()
     # the batch of a step as S sub-batches (contiguous halves, input order) on S lanes: stream + workspace each
-    ctx.set_lanes(S)
+    ctx.set_lanes(S * PIPE)
     cut = [args.reads * j // S for j in range(S + 1)]
-    batches = [ctx.batch_from_codes(codes[cut[j]:cut[j + 1]]) for j in range(S)]
-    log("%d reads generated, packed and uploaded as %d sub-batch(es) in %.1fs" % (args.reads, S, time.time() - t1))
+    sets = [[ctx.batch_from_codes(codes[cut[j]:cut[j + 1]]) for j in range(S)] for _ in range(PIPE)]    # PIPE copies of the step's batch
+    batches = sets[0]
+    log("%d reads generated, packed and uploaded as %d sub-batch(es), %d batch(es) in flight, in %.1fs" % (args.reads, S, PIPE, time.time() - t1))
 
     chain = torch.zeros(1, dtype=torch.int64, device=dev if args.backend == "nccl" else "cpu")
     wall = {"search": 0.0, "select_hard": 0.0, "select_easy": 0.0, "locate": 0.0, "bt_union": 0.0}
 
-    def step():
+    wall_mu = threading.Lock()
+
+    def step(batches, my_turn=None):
         """one pass of the hot path over the whole batch.  Every sub-batch has a thread (ctypes calls release the GIL):
         search -> [its turn in the tie-break stream: sub-batches, then ranks, in input order] -> bulk selection -> SA walk, MAPQ,
         DP.  The search kernels of the two lanes overlap on the GPU (the second fills the CUs the first one's last long reads
@@ -328,6 +335,8 @@ def main():
         th = [threading.Thread(target=lane, args=(j,)) for j in range(S)]
         for t in th:
             t.start()
+        if my_turn is not None:
+            my_turn("submitted")
 
         def advance(before):                 # the tie-break stream through this rank's sub-batches, in input order
             for j in range(S):
@@ -340,7 +349,13 @@ def main():
                 chosen[j].set()
             return before
         try:
-            sharding.chain_stream_position(dist, rank, world, chain, advance)
+            if my_turn is not None:
+                my_turn("wait")              # steps take the tie-break chain (a message between ranks) in step order
+            try:
+                sharding.chain_stream_position(dist, rank, world, chain, advance)
+            finally:
+                if my_turn is not None:
+                    my_turn("done")
         finally:
             for e in chosen:
                 e.set()
@@ -348,11 +363,56 @@ def main():
                 t.join()
         if err:
             raise err[0]
-        for k in ("search", "select_hard", "select_easy", "locate"):
-            wall[k] += max(tw[j].get(k, 0.0) for j in range(S))
         tms = [b.timing() for b in batches]
-        wall["bt_union"] += (max(t["bt_end_ms"] for t in tms) - min(t["bt_begin_ms"] for t in tms)) * 1e-3
+        with wall_mu:
+            for k in ("search", "select_hard", "select_easy", "locate"):
+                wall[k] += max(tw[j].get(k, 0.0) for j in range(S))
+            wall["bt_union"] += (max(t["bt_end_ms"] for t in tms) - min(t["bt_begin_ms"] for t in tms)) * 1e-3
         return tms
+
+    def run_steps(n):
+        """n steps; with PIPE == 2 they alternate between the two batches, each driven by its own thread: step k+1's search
+        launch is submitted while step k's kernel still runs (not before it has had the GPU to itself for a moment: two
+        launches submitted together would share the CUs from the start) and its workgroups start where step k's retire;
+        step k's short later stages run inside that hand-over.  Results are per step, in step order."""
+        if PIPE == 1:
+            return [step(sets[0]) for _ in range(n)]
+        out, errs = [None] * n, []
+        cv = threading.Condition()
+        state = {"turn": 0, "submitted": [None] * n}
+
+        def driver(p):
+            if dev.type == "cuda":
+                torch.cuda.set_device(dev)   # the current device is per thread (the chain's message may be a GPU tensor)
+            for k in range(p, n, PIPE):
+                def my_turn(what, k=k):
+                    with cv:
+                        if what == "submitted":
+                            state["submitted"][k] = time.perf_counter(); cv.notify_all()
+                        elif what == "wait":
+                            cv.wait_for(lambda: state["turn"] == k or errs)
+                        else:
+                            state["turn"] = k + 1; cv.notify_all()
+                try:
+                    if k > 0:
+                        with cv:
+                            cv.wait_for(lambda: state["submitted"][k - 1] is not None or errs)
+                        if errs:
+                            return
+                        time.sleep(max(0.0, state["submitted"][k - 1] + 0.05 - time.perf_counter()))
+                    out[k] = step(sets[p], my_turn)
+                except Exception as e:       # noqa: BLE001
+                    with cv:
+                        errs.append(e); state["turn"] = n + 1; cv.notify_all()
+                    return
+        th = [threading.Thread(target=driver, args=(p,)) for p in range(PIPE)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if errs:
+            raise errs[0]
+        return out
 
     def sync():
         torch.cuda.synchronize()
@@ -360,15 +420,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    run_steps(args.warmup)
     sync()
     for k in wall:
         wall[k] = 0.0
     acc = {}
     t_start = time.perf_counter()
-    for _ in range(args.steps):
-        for tm in step():
+    for tms in run_steps(args.steps):
+        for tm in tms:
             for k, v in tm.items():
                 acc[k] = acc.get(k, 0) + v
     sync()
@@ -380,7 +439,8 @@ def main():
 
     if args.dump_hits:
         os.makedirs(args.dump_hits, exist_ok=True)
-        np.save(os.path.join(args.dump_hits, "hits_rank%d.npy" % rank), np.concatenate([b.hits() for b in batches]))
+        last = sets[(max(1, args.steps) - 1) % PIPE]          # the batch the last timed step ran on
+        np.save(os.path.join(args.dump_hits, "hits_rank%d.npy" % rank), np.concatenate([b.hits() for b in last]))
     if rank == 0:
         K = max(1, args.steps)
         # ---- counters: the timed kernel carries none.  One more, untimed pass of the search stage with the counting kernel,
@@ -395,8 +455,10 @@ def main():
                 for k, v in b.kstats(which).items():
                     dst[k] = dst.get(k, 0) + v
         ctx.set_stats(False)
-        for b in batches:                   # leave the batches searched with the timed kernel, selected and located (hits below)
-            b.run(threads)
+        solo_timed_ms = 0.0
+        for b in batches:                   # leave the batches searched with the timed kernel, selected and located (hits below);
+            b.run(threads)                  # this pass is also the timed kernel ALONE on the GPU: nothing else is in flight
+            solo_timed_ms += b.timing()["ms_backtrack"]
         ks_sa = {}
         for b in batches:
             for k, v in b.kstats(2).items():
@@ -404,6 +466,11 @@ def main():
         n_bt = max(1, acc["n_backtrack_launches"])
         ms_bt_sum_step = acc["ms_backtrack"] / K          # summed over the launches of a step (two lanes overlap in time)
         ms_bt_union_step = 1e3 * wall["bt_union"] / K       # first launch's start to last launch's end: the time the kernel had the GPU
+        if PIPE > 1:
+            # launches of consecutive steps overlap (a launch is submitted while its predecessor runs and its events bracket the
+            # wait for free CUs too): the kernel's own duration is taken from the solo pass above, same kernel, same batch
+            ms_bt_union_step = solo_timed_ms
+            ms_bt_sum_step = solo_timed_ms
         ms_w_step = acc["ms_width"] / K
         # algorithmic bytes: 64 B x distinct Occ blocks touched by the search steps
         alg_bt = 64.0 * (2 * ks_bt["occ_pairs"] - ks_bt["occ_same_blk"])
@@ -425,7 +492,7 @@ def main():
                                    "error-profile seed + banded extension" if args.workload == "full" else "exact-match seed only",
                                    args.genome_mbp),
                        "reads_per_gpu": args.reads, "read_len": args.read_len, "genome_mbp": args.genome_mbp,
-                       "mode": args.workload, "penalty": args.penalty, "sub_batches": S,
+                       "mode": args.workload, "penalty": args.penalty, "sub_batches": S, "pipeline": PIPE,
                        "parallelism": "reads sharded x%d, index replicated" % world},
             "value_scope": "search + samse stages on reads already packed in HBM -> per-read alignment records in pinned host memory "
                            "(FASTQ parsing, upload and SAM text are outside; see value_e2e)",
@@ -436,15 +503,25 @@ def main():
                          "launches_per_step": launches_per_step,
                          "kernel_ms_per_step_union": ms_bt_union_step if dominant_bt else ms_w_step,
                          "kernel_ms_per_step_sum_of_launches": ms_bt_sum_step if dominant_bt else ms_w_step,
-                         "kernel_ms_per_step_launches_alone": solo_ms if dominant_bt else ms_w_step,
+                         "kernel_ms_per_step_launches_alone": solo_timed_ms if dominant_bt else ms_w_step,
+                         "counting_kernel_ms_per_step": solo_ms,
                          "avg_launch_ms": (ms_bt_sum_step if dominant_bt else ms_w_step) / launches_per_step,
-                         "timing": "HIP events on each lane's own stream around every launch of the timed steps; the two lanes' launches overlap, "
-                                   "so achieved = bytes of a step / (first launch's start to last launch's end); counters from one extra "
-                                   "untimed pass of the counting kernel over the same batch",
+                         "timing": ("HIP events on the launch's own stream.  Steps are pipelined (config.pipeline = 2): the launch of step k+1 is in the queue "
+                                    "while step k's kernel runs, so events around the timed launches would include that wait; avg_launch_ms is the same "
+                                    "kernel over the same batch run ALONE right after the timed region (it agrees with rocprofv3 --stats of "
+                                    "`bench.py --pipeline 1`), achieved = bytes of a launch / that duration.  Because a launch fills the CUs its "
+                                    "predecessor's retiring workgroups leave, ms_per_step can be shorter than one launch alone"
+                                    if PIPE > 1 else
+                                    "HIP events on each lane's own stream around every launch of the timed steps; with two sub-batches the lanes' launches "
+                                    "overlap and achieved = bytes of a step / (first launch's start to last launch's end)") +
+                                   "; counters from one extra untimed pass of the counting kernel over the same batch",
                          "width_kernel": {"achieved": alg_w / (ms_w_step * 1e-3) / 1e9, "frac": alg_w / (ms_w_step * 1e-3) / 1e9 / 8000.0}},
             "kernels_ms_per_step": {k: acc[k] / K for k in ("ms_width", "ms_backtrack", "ms_select", "ms_sa2pos",
                                                             "ms_refine", "ms_host_post", "ms_classify", "ms_sel_hard", "ms_sel_easy")},
             "stage_wall_ms_per_step": {k: 1e3 * v / K for k, v in wall.items()},
+            "note_pipelined_timings": ("config.pipeline = 2: the per-stage and per-kernel times above are taken on steps that overlap in time -- ms_backtrack "
+                                       "there brackets the launch's wait for free CUs as well, stage walls add up to more than ms_per_step; the kernel alone is "
+                                       "roofline.avg_launch_ms") if PIPE > 1 else None,
             "kstats": {"backtrack": ks_bt, "width": ks_w, "sa2pos": ks_sa},
             "mapped_frac": float((hits["type"] != 0).mean()),
             "overflow_reads": [int(acc["n_overflow_tier1"] / K), int(acc["n_overflow_tier2"] / K)],
@@ -518,8 +595,9 @@ def main():
         # a JNI / argv binding calls.  The staged objects above are released first (ps_map brings its own context).
         if do_e2e:
             try:
-                for b in batches:
-                    b.free()
+                for bs in sets:
+                    for b in bs:
+                        b.free()
                 ctx.close()
                 torch.cuda.empty_cache()
                 t2 = time.time()

@@ -12,10 +12,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def test_two_ranks_bench_rehearsal(tmp_path):
-    """two bench.py ranks (gloo, both on GPU 0), each mapping its shard as two overlapping sub-batches with the tie-break stream
-    chained through sub-batches and ranks: the per-read records of both ranks, concatenated, equal those of ONE process mapping
-    the same reads as one batch.  (RCCL / xGMI itself cannot run on the one-GPU test box: no N > 1 hardware number exists.)"""
+@pytest.mark.parametrize("mode", ["sub_batches", "pipeline"])
+def test_two_ranks_bench_rehearsal(tmp_path, mode):
+    """two bench.py ranks (gloo, both on GPU 0) with the tie-break stream chained through the ranks -- "sub_batches": each rank maps
+    its shard as two overlapping sub-batches (the chain also runs through them); "pipeline": the default, consecutive steps
+    alternate between two batches in flight and take the chain in step order.  The per-read records of both ranks,
+    concatenated, equal those of ONE process mapping the same reads as one batch.  (RCCL / xGMI itself cannot run on the
+    one-GPU test box: no N > 1 hardware number exists.)"""
     import numpy as np
     import torch
     sys.path.insert(0, ROOT)
@@ -25,13 +28,15 @@ def test_two_ranks_bench_rehearsal(tmp_path):
     dump = str(tmp_path / "hits")
     mbp, n_reads = 8, 60000
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29655", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu",
-           "--genome-mbp", str(mbp), "--contigs", "4", "--reads", str(n_reads), "--steps", "1", "--warmup", "1", "--cpu-sample", "0", "--sub-batches", "2", "--dump-hits", dump]
+           "--master-port", "29655" if mode == "sub_batches" else "29657", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu",
+           "--genome-mbp", str(mbp), "--contigs", "4", "--reads", str(n_reads), "--cpu-sample", "0", "--dump-hits", dump]
+    cmd += ["--steps", "1", "--warmup", "1", "--sub-batches", "2"] if mode == "sub_batches" else ["--steps", "4", "--warmup", "1"]
     r = subprocess.run(cmd, env=env, timeout=900, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.split("\n") if l.startswith("{")][-1]
     d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["config"]["sub_batches"] == 2
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert (d["config"]["sub_batches"], d["config"]["pipeline"]) == ((2, 1) if mode == "sub_batches" else (1, 2))
     assert d["mapped_frac"] > 0.8
     got = np.concatenate([np.load(os.path.join(dump, "hits_rank%d.npy" % k)) for k in range(2)])
     # the same genome and the same reads (rank r draws its reads from seed 0x5EED0003 + r), one process, one batch

@@ -23,9 +23,12 @@ P = np.array(bench.PROFILE); P[3, 1], P[3, 3] = 0.12, 0.87
 with open('/tmp/e2e.errorprofile', 'w') as f:
     for row in P: f.write(''.join(repr(float(v)) + '\t' for v in row) + '\n')
 open('/tmp/e2e.indelprofile', 'w').write('2.1E-5\t5.9E-4')
-for rep in range(2):
+workers = [int(x) for x in sys.argv[3].split(',')] if len(sys.argv) > 3 else [1]      # PS_WORKERS_PER_GPU settings to time
+for w, rep in [(w, r) for w in workers for r in range(2)]:
+    os.environ['PS_WORKERS_PER_GPU'] = str(w)
+    print('PS_WORKERS_PER_GPU=%d' % w, flush=True)
     t = time.time(); os.environ['PS_VERBOSE']='1'; capi.ps_map(16, '-1', '/tmp/e2e.errorprofile', '/tmp/e2e.indelprofile', fa, fq, '/tmp/e2e.sam'); dt = time.time() - t
     print('ps_map (index load + %d reads + SAM written) %.2fs = %.2f M reads/s, SAM %.0f MB' % (n, dt, n / dt / 1e6, os.path.getsize('/tmp/e2e.sam') / 1e6), flush=True)
-for args in (dict(min_mapq=10), dict(min_mapq=10, sort_by_coordinate=True, write_index=True)):
+for args in (() if len(sys.argv) > 4 and sys.argv[4] == 'nobam' else (dict(min_mapq=10), dict(min_mapq=10, sort_by_coordinate=True, write_index=True))):
     t = time.time(); st = capi.ps_sam_to_bam('/tmp/e2e.sam', '/tmp/e2e.bam', threads=16, **args); dt = time.time() - t
     print('ps_sam_to_bam %s: %.2fs, %d of %d records kept, BAM %.0f MB' % (args, dt, st['n_out'], st['n_in'], st['bam_bytes'] / 1e6), flush=True)
