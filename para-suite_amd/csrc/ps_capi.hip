@@ -381,7 +381,7 @@ static int map_core(int threads, const char *mm, const char *error_profile, cons
             if (f) {
                 if (fseeko(f, 0, SEEK_END) == 0) {
                     const off_t sz = ftello(f);
-                    if (sz > 0) chunk_bytes = std::min(chunk_bytes, std::max<size_t>((size_t)16 << 20, ((size_t)sz + 2 * (size_t)n_workers - 1) / (2 * (size_t)n_workers)));
+                    if (sz > 0) chunk_bytes = std::min(chunk_bytes, std::max<size_t>((size_t)16 << 20, ((size_t)sz + 2 * (size_t)n_workers - 1) / (2 * (size_t)n_workers) + ((size_t)64 << 10)));   // + slack: cuts fall behind whole records, the last piece must not be a few reads
                 }
                 std::fclose(f);
             }
