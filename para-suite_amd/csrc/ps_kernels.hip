@@ -274,6 +274,10 @@ __global__ void __launch_bounds__(256, PS_BT_WAVES) k_backtrack_n(const BtArgs *
         st.pops = lane == 0 ? (uint32_t)(clk.tm[2] >> 6) : 0; st.exact = lane == 0 ? (uint32_t)(clk.tm[3] >> 6) : 0;
 #endif
         flush_stats(a.stats, st);
+    } else {
+        // the timed kernel keeps two counters: the Occ steps it made and those that needed one block only (ps_narrow.h, nt_occ)
+        st.nodes = st.pushes = st.pops = st.iters = st.exact = st.lf = 0;
+        flush_stats(a.stats, st);
     }
 }
 

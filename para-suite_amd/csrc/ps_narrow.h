@@ -130,14 +130,21 @@ PS_HD void nt_occ(const BtHot &h, uint32_t c, uint32_t kr, uint32_t lr, uint32_t
     Blk xl, xk;
     load_blk(h.blocks, bl, xl);
     if (PS_OCC_COND) {
+        // both blocks are asked for before either is looked at, and the block of row l is counted first: the second one's
+        // load (where there is one) has that long to arrive
         const bool other = bk != bl;
         if (other) load_blk(h.blocks, bk, xk);
+        blk_count4b(xl, ol_ + 1, cl);
 #pragma unroll
         for (int j = 0; j < 16; ++j) xk.x[j] = other ? xk.x[j] : xl.x[j];
-    } else load_blk(h.blocks, bk, xk);
-    blk_count4b(xl, ol_ + 1, cl);
+    } else { load_blk(h.blocks, bk, xk); blk_count4b(xl, ol_ + 1, cl); }
     blk_count4b(xk, rk, ck);
-    if (STATS) { ++st.pairs; if (need_k && bk == bl) ++st.same; }
+    // Block reads of the steps that go through the Occ array (not the jump table's), counted in EVERY build: two adds, and the
+    // timed kernel can say what it asked the memory for.  (They also decide the schedule the compiler picks for this function:
+    // with them it waits for the blocks late and lets the table's loads run on, without them it waits right behind every load --
+    // 1255 ms against 1334 ms per 10 M reads, profiles/r02_kernel_experiments.txt.  A measured property of hipcc 7.2, not a design.)
+    ++st.pairs; if (need_k && bk == bl) ++st.same;
+    (void)STATS;
 }
 
 // text symbols an entry has consumed (its depth in the tree of strings): read bases used, less the inserted ones, plus the deleted

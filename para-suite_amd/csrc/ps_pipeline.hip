@@ -356,7 +356,7 @@ std::unique_ptr<Batch> batch_prepare(Ctx *ctx, ReadSet &&rs_in, int threads)
         // Order the reads of a bin by their leading bases (the search consumes a read from its first base): the
         // lanes of a wave then walk the same top levels of the BWT, so their Occ loads coalesce and hit in cache.
         // Results return to input order through ids[]; the order inside a bin is free.
-        {
+        if (!std::getenv("PS_KEEP_ORDER")) {         // PS_KEEP_ORDER=1: the reads stay in input order (tools/order_probe.py hands them out in an order of its own)
             const size_t n = bin.ids.size();
             std::vector<uint32_t> key(n), key2(n); std::vector<int32_t> id2(n);
             for (size_t r = 0; r < n; ++r) {

@@ -1,7 +1,7 @@
 """order_probe.py -- how much of the search kernel's time is its tail?  (measurement aid, not a product path)
 
 Runs the bench batch once with the counting kernel (per-read iteration counts), then times the search kernel on the same
-reads handed out (a) in input order, (b) longest search first by the TRUE iteration counts (an oracle order: the bound on
+reads handed out (a) in the product's order (by leading bases) and in input order, (b) longest search first by the TRUE iteration counts (an oracle order: the bound on
 what any predictor of a read's cost could gain), (c) longest last (the worst case).
 usage: python tools/order_probe.py [genome_mbp] [reads]"""
 import os
@@ -49,6 +49,8 @@ def timed(order, label):
     del bb
 
 
+timed(None, "leading-base order (the product's)")
+os.environ["PS_KEEP_ORDER"] = "1"          # from here on the library keeps the order it is given
 timed(None, "input order")
 o = np.argsort(-it, kind="stable")
 timed(o, "longest first (true counts)")
