@@ -456,9 +456,12 @@ def main():
                     dst[k] = dst.get(k, 0) + v
         ctx.set_stats(False)
         solo_timed_ms = 0.0
+        ks_timed = {}
         for b in batches:                   # leave the batches searched with the timed kernel, selected and located (hits below);
             b.run(threads)                  # this pass is also the timed kernel ALONE on the GPU: nothing else is in flight
             solo_timed_ms += b.timing()["ms_backtrack"]
+            for k, v in b.kstats(1).items():    # the timed kernel counts the steps it takes through the Occ array (the others: jump table)
+                ks_timed[k] = ks_timed.get(k, 0) + v
         ks_sa = {}
         for b in batches:
             for k, v in b.kstats(2).items():
@@ -515,6 +518,11 @@ def main():
                                     "HIP events on each lane's own stream around every launch of the timed steps; with two sub-batches the lanes' launches "
                                     "overlap and achieved = bytes of a step / (first launch's start to last launch's end)") +
                                    "; counters from one extra untimed pass of the counting kernel over the same batch",
+                         "requested_bytes_per_step": (64.0 * (2 * ks_timed.get("occ_pairs", 0) - ks_timed.get("occ_same_blk", 0)) +
+                                                      32.0 * max(0, ks_bt["occ_pairs"] - ks_timed.get("occ_pairs", 0))) if dominant_bt else None,
+                         "requested_bytes_note": "what the timed kernel asks the memory for in search steps: 64 B per distinct Occ block of the steps it takes through "
+                                                 "the Occ array (its own two counters) + 32 B per step answered by the jump table (DESIGN.md section 2); the algorithmic "
+                                                 "bytes above are those of the reference's algorithm, counted without the table",
                          "width_kernel": {"achieved": alg_w / (ms_w_step * 1e-3) / 1e9, "frac": alg_w / (ms_w_step * 1e-3) / 1e9 / 8000.0}},
             "kernels_ms_per_step": {k: acc[k] / K for k in ("ms_width", "ms_backtrack", "ms_select", "ms_sa2pos",
                                                             "ms_refine", "ms_host_post", "ms_classify", "ms_sel_hard", "ms_sel_easy")},
@@ -522,7 +530,7 @@ def main():
             "note_pipelined_timings": ("config.pipeline = 2: the per-stage and per-kernel times above are taken on steps that overlap in time -- ms_backtrack "
                                        "there brackets the launch's wait for free CUs as well, stage walls add up to more than ms_per_step; the kernel alone is "
                                        "roofline.avg_launch_ms") if PIPE > 1 else None,
-            "kstats": {"backtrack": ks_bt, "width": ks_w, "sa2pos": ks_sa},
+            "kstats": {"backtrack": ks_bt, "width": ks_w, "sa2pos": ks_sa, "backtrack_timed_kernel": ks_timed},
             "mapped_frac": float((hits["type"] != 0).mean()),
             "overflow_reads": [int(acc["n_overflow_tier1"] / K), int(acc["n_overflow_tier2"] / K)],
         }
