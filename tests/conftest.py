@@ -4,6 +4,11 @@ import sys
 import numpy as np
 import pytest
 
+try:                       # PyTorch-ROCm brings its own copy of the HIP runtime: in a process that uses both, torch has to be imported
+    import torch  # noqa: F401   # BEFORE libparasuite_hip.so is loaded (the library then binds to the runtime already there); the
+except ImportError:        # other order leaves torch without a device ("no ROCm-capable device is detected")
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (os.path.join(ROOT, "para-suite_amd"), os.path.join(ROOT, "oracle"), ROOT):
     if p not in sys.path:
