@@ -52,8 +52,10 @@ int     ps_ctx_set_stock(ps_ctx *, const char *n_arg);               /* bwa aln 
 int     ps_ctx_set_profile(ps_ctx *, const char *error_profile, const char *indel_profile, const char *x_arg);
 int     ps_ctx_set_profile_matrix(ps_ctx *, const double P[16], double ins_rate, double del_rate, int x);
 int     ps_ctx_set_tiers(ps_ctx *, const uint32_t pool_cap[3], const int32_t aln_cap[3], int bt_blocks);
-/* measurement runs: the search kernel of the following launches counts its Occ lookups, pushes, pops ... (ps_batch_kstats,
- * which = 1); the default kernel carries no counters and leaves them zero */
+/* measurement runs: the search kernel of the following launches counts its search steps, pushes, pops ... and walks the plain Occ
+ * blocks (no jump table): the counts are those of the reference algorithm (ps_batch_kstats, which = 1).  The default kernel
+ * keeps two counters only -- occ_pairs / occ_same_blk of the steps IT takes through the Occ array (the rest go through the
+ * jump table) -- and leaves the others zero */
 int     ps_ctx_set_stats(ps_ctx *, int on);
 /* lanes of work (stream + workspace) the batches created afterwards take in turn: 1 (default) or 2 -- two batches on two lanes may
  * be driven from two threads at once, one's selection / SA walk / DP stages then run under the other's search kernel */
