@@ -302,117 +302,121 @@ def main():
     chain = torch.zeros(1, dtype=torch.int64, device=dev if args.backend == "nccl" else "cpu")
     wall = {"search": 0.0, "select_hard": 0.0, "select_easy": 0.0, "locate": 0.0, "bt_union": 0.0}
 
-    wall_mu = threading.Lock()
+    class Step:
+        """one pass of the hot path over the whole batch, in three parts.  start(): every sub-batch gets a thread (ctypes calls
+        release the GIL) that runs search -> [waits for its turn in the tie-break stream] -> bulk selection -> SA walk, MAPQ, DP.
+        chain(): on the CALLING thread (always the main one: every torch.distributed call of this program is made there, in step
+        order) the tie-break stream goes through this rank's sub-batches, then on to the next rank.  finish(): joins, returns the
+        sub-batches' timings."""
 
-    def step(batches, my_turn=None):
-        """one pass of the hot path over the whole batch.  Every sub-batch has a thread (ctypes calls release the GIL):
-        search -> [its turn in the tie-break stream: sub-batches, then ranks, in input order] -> bulk selection -> SA walk, MAPQ,
-        DP.  The search kernels of the two lanes overlap on the GPU (the second fills the CUs the first one's last long reads
-        leave idle), and one sub-batch's later stages run under the other's search kernel."""
-        searched = [threading.Event() for _ in range(S)]
-        chosen = [threading.Event() for _ in range(S)]
-        err = []
-        tw = [dict() for _ in range(S)]
+        def __init__(self, batches):
+            self.batches = batches
+            self.searched = [threading.Event() for _ in range(S)]
+            self.chosen = [threading.Event() for _ in range(S)]
+            self.err = []
+            self.tw = [dict() for _ in range(S)]
+            self.th = []
+            self.submitted = None
 
-        def lane(j):
+        def _lane(self, j):
+            b, tw = self.batches[j], self.tw[j]
             try:
                 t0 = time.perf_counter()
-                batches[j].search()
-                tw[j]["search"] = time.perf_counter() - t0
-                searched[j].set()
-                chosen[j].wait()
-                if err:
+                b.search()
+                tw["search"] = time.perf_counter() - t0
+                self.searched[j].set()
+                self.chosen[j].wait()
+                if self.err:
                     return
                 t1 = time.perf_counter()
-                batches[j].select_easy(threads)
+                b.select_easy(threads)
                 t2 = time.perf_counter()
-                batches[j].locate()
-                tw[j]["select_easy"] = t2 - t1; tw[j]["locate"] = time.perf_counter() - t2
-            except Exception as e:           # noqa: BLE001 -- reported below, the other lane is released
-                err.append(e)
-                searched[j].set()
+                b.locate()
+                tw["select_easy"] = t2 - t1; tw["locate"] = time.perf_counter() - t2
+            except Exception as e:           # noqa: BLE001 -- reported by finish(), the other lane is released
+                self.err.append(e)
+                self.searched[j].set()
 
-        th = [threading.Thread(target=lane, args=(j,)) for j in range(S)]
-        for t in th:
-            t.start()
-        if my_turn is not None:
-            my_turn("submitted")
+        def start(self):
+            self.th = [threading.Thread(target=self._lane, args=(j,)) for j in range(S)]
+            for t in self.th:
+                t.start()
+            self.submitted = time.perf_counter()
 
-        def advance(before):                 # the tie-break stream through this rank's sub-batches, in input order
-            for j in range(S):
-                searched[j].wait()
-                if err:
-                    break
-                t0 = time.perf_counter()
-                before = batches[j].select_hard(before)
-                tw[j]["select_hard"] = time.perf_counter() - t0
-                chosen[j].set()
-            return before
-        try:
-            if my_turn is not None:
-                my_turn("wait")              # steps take the tie-break chain (a message between ranks) in step order
+        def chain(self):
+            def advance(before):             # the tie-break stream through this rank's sub-batches, in input order
+                for j in range(S):
+                    self.searched[j].wait()
+                    if self.err:
+                        break
+                    t0 = time.perf_counter()
+                    before = self.batches[j].select_hard(before)
+                    self.tw[j]["select_hard"] = time.perf_counter() - t0
+                    self.chosen[j].set()
+                return before
             try:
                 sharding.chain_stream_position(dist, rank, world, chain, advance)
             finally:
-                if my_turn is not None:
-                    my_turn("done")
-        finally:
-            for e in chosen:
+                for e in self.chosen:
+                    e.set()
+
+        def finish(self):
+            for e in self.chosen:
                 e.set()
-            for t in th:
+            for t in self.th:
                 t.join()
-        if err:
-            raise err[0]
-        tms = [b.timing() for b in batches]
-        with wall_mu:
+            if self.err:
+                raise self.err[0]
+            tms = [b.timing() for b in self.batches]
             for k in ("search", "select_hard", "select_easy", "locate"):
-                wall[k] += max(tw[j].get(k, 0.0) for j in range(S))
+                wall[k] += max(self.tw[j].get(k, 0.0) for j in range(S))
             wall["bt_union"] += (max(t["bt_end_ms"] for t in tms) - min(t["bt_begin_ms"] for t in tms)) * 1e-3
-        return tms
+            return tms
 
     def run_steps(n):
-        """n steps; with PIPE == 2 they alternate between the two batches, each driven by its own thread: step k+1's search
-        launch is submitted while step k's kernel still runs (not before it has had the GPU to itself for a moment: two
-        launches submitted together would share the CUs from the start) and its workgroups start where step k's retire;
-        step k's short later stages run inside that hand-over.  Results are per step, in step order."""
+        """n steps, results in step order.  With PIPE == 2 consecutive steps alternate between the two batches: step k+1 is
+        started -- its search launch submitted -- as soon as its batch is free (step k-1 finished) and step k's launch has had the
+        GPU to itself for a moment (two launches submitted together share the CUs from the start), i.e. while step k's kernel
+        still runs: its workgroups start where step k's retire, and step k's short later stages run inside that hand-over."""
+        out = []
         if PIPE == 1:
-            return [step(sets[0]) for _ in range(n)]
-        out, errs = [None] * n, []
-        cv = threading.Condition()
-        state = {"turn": 0, "submitted": [None] * n}
-
-        def driver(p):
-            if dev.type == "cuda":
-                torch.cuda.set_device(dev)   # the current device is per thread (the chain's message may be a GPU tensor)
-            for k in range(p, n, PIPE):
-                def my_turn(what, k=k):
-                    with cv:
-                        if what == "submitted":
-                            state["submitted"][k] = time.perf_counter(); cv.notify_all()
-                        elif what == "wait":
-                            cv.wait_for(lambda: state["turn"] == k or errs)
-                        else:
-                            state["turn"] = k + 1; cv.notify_all()
+            for _ in range(n):
+                st = Step(sets[0]); st.start()
                 try:
-                    if k > 0:
-                        with cv:
-                            cv.wait_for(lambda: state["submitted"][k - 1] is not None or errs)
-                        if errs:
-                            return
-                        time.sleep(max(0.0, state["submitted"][k - 1] + 0.05 - time.perf_counter()))
-                    out[k] = step(sets[p], my_turn)
-                except Exception as e:       # noqa: BLE001
-                    with cv:
-                        errs.append(e); state["turn"] = n + 1; cv.notify_all()
-                    return
-        th = [threading.Thread(target=driver, args=(p,)) for p in range(PIPE)]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-        if errs:
-            raise errs[0]
-        return out
+                    st.chain()
+                finally:
+                    out.append(st.finish())
+            return out
+        steps = [None] * n
+        done = [False] * n
+
+        def begin(k):
+            if k >= PIPE and not done[k - PIPE]:
+                out_k = steps[k - PIPE].finish(); done[k - PIPE] = True      # the batch is free when its previous step is through
+                results[k - PIPE] = out_k
+            if k > 0:
+                time.sleep(max(0.0, steps[k - 1].submitted + 0.05 - time.perf_counter()))
+            steps[k] = Step(sets[k % PIPE]); steps[k].start()
+        results = [None] * n
+        try:
+            if n:
+                begin(0)
+            for k in range(n):
+                if k + 1 < n:
+                    begin(k + 1)
+                steps[k].chain()
+            for k in range(n):
+                if not done[k]:
+                    results[k] = steps[k].finish(); done[k] = True
+        except BaseException:
+            for k in range(n):               # release whatever still waits
+                if steps[k] is not None and not done[k]:
+                    try:
+                        steps[k].finish()
+                    except Exception:        # noqa: BLE001
+                        pass
+            raise
+        return results
 
     def sync():
         torch.cuda.synchronize()
