@@ -144,6 +144,7 @@ void batch_upload(Batch &b);                                                  //
 void batch_search(Batch &b);                                    // width + backtracking kernels (+ larger tiers), hit lists to host
 void batch_select_hard(Batch &b, uint64_t draws_before, uint64_t *draws_after);
 void batch_select_easy(Batch &b, int threads);
+void reserve_search_workspace(Ctx *ctx, int work_index);        // the big device allocations of a lane of work, ahead of its first search
 void batch_locate(Batch &b);                                    // SA walk kernel, strand / MAPQ, banded DP of gapped hits
 void batch_write_sam(Batch &b, const char *path, bool header, const char *pg_line, int threads, bool append = false);
 // the located hits with MAPQ >= min_mapq as records for the error-profile kernel (what the MAPQ-filtered BAM of the first pass holds:

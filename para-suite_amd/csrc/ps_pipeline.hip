@@ -711,6 +711,27 @@ __global__ void k_post(PostArgs a)
     }
 }
 
+// The big allocations of a lane of work (tier-1 stack slices, the large stack slots) made ahead of its first search: a
+// hipMalloc of tens of GB synchronises the device, so when a second worker makes its own while the first worker's search kernel
+// runs it waits for that kernel (seen as a 1-2 s stall of a piece).  ps_map calls this when a worker starts, before any search.
+void reserve_search_workspace(Ctx *ctx, int work_index)
+{
+    require_device(ctx->device);
+    Work *wk = ctx->work_at(work_index);
+    int dev_cus = 256;
+    { hipDeviceProp_t p; if (hipGetDeviceProperties(&p, ctx->device) == hipSuccess && p.multiProcessorCount > 0) dev_cus = p.multiProcessorCount; }
+    const uint32_t pool_cap = ctx->pool_cap[0];
+    if (pool_cap > 65535) return;                             // first tier is the wide one: sized by the launch
+    int blocks = ctx->bt_blocks > 0 ? ctx->bt_blocks : dev_cus * 4;
+    const size_t per_lane = (size_t)pool_cap * 16, max_lanes = ((size_t)64 << 30) / per_lane;
+    if ((size_t)blocks * 256 > max_lanes) blocks = (int)std::max<size_t>(1, max_lanes / 256);
+    (void)wk->ws_get<uint8_t>("pool", (size_t)blocks * 256 * per_lane);
+    if (pool_cap < 65535 && ctx->n_big > 0) {
+        (void)wk->ws_get<uint8_t>("big_pool", (size_t)ctx->n_big * 65535 * 16);
+        (void)wk->ws_get<uint32_t>("big_busy", (size_t)ctx->n_big);
+    }
+}
+
 // --------------------------------------------------------------- search stage -------
 void batch_search(Batch &b)
 {
