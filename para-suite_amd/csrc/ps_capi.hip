@@ -474,7 +474,7 @@ static int map_core(int threads, const char *mm, const char *error_profile, cons
             try {
                 Ctx &c = xs[g]->c;
                 require_device(c.device);
-                reserve_search_workspace(&c, j);                       // before any search kernel runs on this device
+                if (dev_workers[g] > 1) reserve_search_workspace(&c, j);   // several workers on one device: before any search kernel runs on it
                 if (j == 0) {                                          // this device's index: from the files, or from the first device
                     if (g == 0) { index_load(ref_fa, c.ix, c.stream); t_index = since(); }
                     else {
