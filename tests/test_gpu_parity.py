@@ -219,6 +219,51 @@ def test_reference_accuracy_rule(ctx_mid, mid, workdir):
     assert total == 6000 and mapped > 0.9 * total and correct > 0.99 * mapped
 
 
+def test_config0_refine_run_100k_reads(example, workdir):
+    """BASELINE configs[0]'s shape -- ~100 k x 50 bp simulated PAR-CLIP reads against the (regenerated) example reference -- as the
+    whole `--refine` sequence of Main.java:283-340 through the mirror classes: first pass with stock costs, error profile from its
+    MAPQ-filtered alignments (fused into the pass), second pass with that profile.  Every file is compared with the oracle run on
+    the same inputs: both SAM files line by line, the two profile files byte for byte."""
+    import ctypes as C
+    import shutil
+    import __graft_entry__ as ge
+    import orc
+    import simulate as S
+    mod = ge.load_package()
+    d = os.path.join(workdir, "cfg0")
+    os.makedirs(d, exist_ok=True)
+    fa = os.path.join(d, "example.fa")
+    shutil.copy(example["fa"], fa)
+    sim = S.simulate_reads(example["genome"], n_reads=100000, read_len=50, seed=1000, indel_scale=100, n_frac=0.001)
+    fq = os.path.join(d, "reads.fq")
+    S.write_fastq(fq, sim)
+    oix = example["orc_index"]
+    # first pass (BWAMapping: stock `aln -n 2`) + the profile of its MAPQ >= 10 alignments
+    m1 = mod.mapping.BWAMapping()
+    ep, ip = m1.executeMappingWithProfile(8, fa, fq, os.path.join(d, "first"), 10, "2", 101)
+    o1 = os.path.join(d, "first.orc.sam")
+    oix.map_fastq(orc.stock_opt("2"), fq, o1, n_threads=8)
+    assert sam_records(os.path.join(d, "first.sam")) == sam_records(o1)
+    mod.mapping.Mapping.filter_sam_mapq(o1, os.path.join(d, "first.orc.q10.sam"), 10)
+    orc.error_profile(os.path.join(d, "first.orc.q10.sam"), fa, 101, os.path.join(d, "orc"))
+    assert open(ep, "rb").read() == open(os.path.join(d, "orc.errorprofile"), "rb").read()
+    assert open(ip, "rb").read() == open(os.path.join(d, "orc.indelprofile"), "rb").read()
+    # refine pass (PARAsuiteMapping) on the estimated profile
+    m2 = mod.mapping.PARAsuiteMapping()
+    m2.setErrorProfileFilename(ep)
+    m2.setIndelProfileFilename(ip)
+    m2.executeMapping(8, fa, fq, os.path.join(d, "refine"), 10, "-1")
+    P = (C.c_double * 16)()
+    a, b = C.c_double(), C.c_double()
+    assert orc.lib().orc_read_profile_files(ep.encode(), ip.encode(), P, C.byref(a), C.byref(b)) == 0
+    o2 = os.path.join(d, "refine.orc.sam")
+    oix.map_fastq(orc.profile_opt(list(P), a.value, b.value, -1), fq, o2, n_threads=8)
+    got = sam_records(os.path.join(d, "refine.sam"))
+    assert got == sam_records(o2)
+    mapped = sum(1 for l in got if not int(l.split("\t")[1]) & 4)
+    assert mapped > 0.7 * len(got) and len(got) == 100000
+
+
 def test_stack_growth_in_launch(ctx_example, example, workdir):
     """a private stack slice of 64 entries: almost every read moves to a large slot inside the launch
     (wave-cooperative copy) and none needs the next tier; results unchanged"""
