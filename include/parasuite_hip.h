@@ -108,6 +108,9 @@ int64_t ps_ctx_read_iters(ps_ctx *, uint32_t *out, int64_t cap);   /* profiling 
 int     ps_batch_kstats(ps_batch *, int which /*0 width 1 backtrack 2 sa2pos*/, ps_kstats *out);
 /* host-only check of the read parser: whole file on `threads` threads (chunk_bytes 0) or streamed in windows of chunk_bytes as
  * ps_map does; out = {reads, bases, order-sensitive hash of names / sequences / qualities, pieces} */
+/* the library keeps up to 3 GB of page-locked host buffers between calls (locking and unlocking them costs ~0.1 s per piece of a
+ * ps_map call); this gives them back */
+void    ps_release_host_cache(void);
 int     ps_parse_check(const char *reads_path, int threads, uint64_t chunk_bytes, uint64_t out[4]);
 
 /* ---- after the map step --------------------------------------------------------------

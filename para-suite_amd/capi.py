@@ -44,7 +44,7 @@ EXPORTS = ["ps_version", "ps_last_error", "ps_index", "ps_map", "ps_ctx_open", "
            "ps_ctx_blob", "ps_ctx_meta", "ps_ctx_from_blobs", "ps_ctx_fetch", "ps_ctx_export_blob", "ps_ctx_sa_lookup", "ps_sam_to_bam", "ps_bam_view", "ps_bam_sort", "ps_bam_index", "ps_batch_from_fastq",
            "ps_batch_from_codes", "ps_batch_free", "ps_batch_n", "ps_batch_search", "ps_batch_select_hard",
            "ps_batch_select_easy", "ps_batch_locate", "ps_batch_run", "ps_batch_write_sam", "ps_batch_n_aln",
-           "ps_batch_alns", "ps_batch_hits", "ps_batch_timing", "ps_batch_kstats", "ps_ctx_read_iters", "ps_parse_check", "ps_error_profile", "ps_map_profiled"]
+           "ps_batch_alns", "ps_batch_hits", "ps_batch_timing", "ps_batch_kstats", "ps_ctx_read_iters", "ps_parse_check", "ps_error_profile", "ps_map_profiled", "ps_release_host_cache"]
 
 _LIB = None
 

@@ -571,6 +571,9 @@ int ps_map_profiled(int threads, const char *mm, const char *error_profile, cons
     return map_core(threads, mm, error_profile, indel_profile, ref_fa, fastq, out_sam, &sink);
 }
 
+// page-locked host buffers the library keeps between calls (ps_pipeline.h, PinBuf): given back to the system
+void ps_release_host_cache(void) { try { pin_cache_release(); } catch (...) {} }
+
 // host-only: parse reads the way ps_map does (whole file on `threads` threads, or streamed in windows of chunk_bytes) and
 // summarise what came out -- {reads, bases, order-sensitive hash of names/sequences/qualities, pieces}
 int ps_parse_check(const char *reads_path, int threads, uint64_t chunk_bytes, uint64_t out[4])

@@ -43,13 +43,19 @@ struct Timing {
     double bt_begin_ms = 0, bt_end_ms = 0;   // first search launch's start / last one's end on the context's clock (overlapping batches: the union)
 };
 
+// Page-locked host memory is dear to get and to give back (hundreds of MB per piece of a ps_map call: ~50 ms to lock, as much to
+// unlock): buffers that are let go are kept, up to a bound, and handed to the next taker (the pieces of one call, the next
+// call of the process).  pin_cache_release() gives everything kept back to the system.
+void *pin_cache_take(size_t need, size_t &got);
+void pin_cache_give(void *p, size_t bytes);
+void pin_cache_release();
 struct PinBuf {                     // page-locked host staging (D2H at PCIe rate instead of pageable copies)
     void *p = nullptr; size_t bytes = 0;
     PinBuf() {}
     PinBuf(const PinBuf &) = delete;
     PinBuf &operator=(const PinBuf &) = delete;
-    ~PinBuf() { if (p) (void)hipHostFree(p); }
-    void *get(size_t need) { if (need > bytes) { if (p) (void)hipHostFree(p); p = nullptr; bytes = 0; PS_HIP(hipHostMalloc(&p, need, hipHostMallocDefault)); bytes = need; } return p; }
+    ~PinBuf() { if (p) pin_cache_give(p, bytes); }
+    void *get(size_t need) { if (need > bytes) { if (p) pin_cache_give(p, bytes); p = nullptr; bytes = 0; p = pin_cache_take(need, bytes); } return p; }
 };
 
 // One lane of work on the device: a stream with its own grow-only device workspace and pinned staging (hipMalloc /

@@ -9,6 +9,7 @@
 // No stage has a CPU implementation of the kernels' work: without a HIP device
 // every entry point fails.
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <hipcub/hipcub.hpp>
 #include <algorithm>
 #include <atomic>
@@ -52,6 +53,51 @@ Work *Ctx::take_work()
     { std::lock_guard<std::mutex> l(work_mu); w = next_work; next_work = (next_work + 1) % std::max(1, std::min(n_work, (int)N_WORK)); }
     return work_at(w);
 }
+namespace {
+struct PinCache {
+    std::mutex mu; std::vector<std::pair<void *, size_t>> kept; size_t held = 0;
+    static constexpr size_t CAP = (size_t)3 << 30;            // bytes kept at most
+};
+PinCache &pin_cache() { static PinCache *c = new PinCache(); return *c; }   // never destroyed: buffers may be given back during exit
+}
+void *pin_cache_take(size_t need, size_t &got)
+{
+    PinCache &c = pin_cache();
+    {
+        std::lock_guard<std::mutex> l(c.mu);
+        int best = -1;
+        for (size_t i = 0; i < c.kept.size(); ++i)            // the smallest kept buffer that fits without wasting more than half of it
+            if (c.kept[i].second >= need && c.kept[i].second <= 2 * need + ((size_t)1 << 20) && (best < 0 || c.kept[i].second < c.kept[(size_t)best].second)) best = (int)i;
+        if (best >= 0) {
+            void *p = c.kept[(size_t)best].first; got = c.kept[(size_t)best].second;
+            c.held -= got; c.kept.erase(c.kept.begin() + best);
+            return p;
+        }
+    }
+    const size_t want = need + need / 8 + 4096;               // a little room: the next piece is rarely exactly as large
+    void *p = nullptr;
+    PS_HIP(hipHostMalloc(&p, want, hipHostMallocDefault));
+    got = want;
+    return p;
+}
+void pin_cache_give(void *p, size_t bytes)
+{
+    if (!p) return;
+    PinCache &c = pin_cache();
+    {
+        std::lock_guard<std::mutex> l(c.mu);
+        if (c.held + bytes <= PinCache::CAP) { c.kept.emplace_back(p, bytes); c.held += bytes; return; }
+    }
+    (void)hipHostFree(p);
+}
+void pin_cache_release()
+{
+    PinCache &c = pin_cache();
+    std::vector<std::pair<void *, size_t>> all;
+    { std::lock_guard<std::mutex> l(c.mu); all.swap(c.kept); c.held = 0; }
+    for (auto &e : all) (void)hipHostFree(e.first);
+}
+
 void Batch::release_device()
 {
     for (Bin &bin : bins) {
