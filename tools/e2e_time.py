@@ -24,6 +24,8 @@ with open('/tmp/e2e.errorprofile', 'w') as f:
     for row in P: f.write(''.join(repr(float(v)) + '\t' for v in row) + '\n')
 open('/tmp/e2e.indelprofile', 'w').write('2.1E-5\t5.9E-4')
 workers = [int(x) for x in sys.argv[3].split(',')] if len(sys.argv) > 3 else [1]      # PS_WORKERS_PER_GPU settings to time
+for kv in sys.argv[5:]:                                                                # further NAME=value settings for the library
+    os.environ[kv.split('=')[0]] = kv.split('=')[1]
 for w, rep in [(w, r) for w in workers for r in range(2)]:
     os.environ['PS_WORKERS_PER_GPU'] = str(w)
     print('PS_WORKERS_PER_GPU=%d' % w, flush=True)
