@@ -665,6 +665,37 @@ struct SelectArgs {
     unsigned long long draws_in;
     SelRec *sel; bwtint *rows; int *err;
 };
+// ---- the choice of a read's main hit (upstream bwa_aln2seq_core), ONE copy for the device kernel and the host-finished reads ----
+// Walks the best-score intervals in list order: every one costs a draw, the one that wins costs a second draw that places the hit
+// inside it.  x is the state of the drand48 stream (advanced by the draws made, whose number is returned); c1 / c2 = occurrences
+// at the best score / at the other listed scores.  IEEE doubles in this order of operations on both sides.
+struct MainPick { bwtint sa; int32_t c1, c2; int type, n_mm, n_gapo, n_gape, ref_shift, score; };
+__host__ __device__ inline unsigned long long lcg48_next(unsigned long long x) { return (x * 0x5DEECE66DULL + 0xBULL) & 0xFFFFFFFFFFFFULL; }
+__host__ __device__ inline int rule_choose_main(const AlnRec *al, int na, unsigned long long &x, MainPick &h)
+{
+    int cnt = 0, draws = 0, i;
+    const int best = al[0].score;
+    h.sa = 0; h.n_mm = h.n_gapo = h.n_gape = h.ref_shift = h.score = 0;
+    for (i = 0; i < na; ++i) {
+        const AlnRec p = al[i];
+        if (p.score > best) break;
+        const unsigned long long wdt = (unsigned long long)(p.l - p.k) + 1ull;
+        x = lcg48_next(x); ++draws;
+        if ((double)x * (1.0 / 281474976710656.0) * (double)(wdt + (unsigned long long)(long long)cnt) > (double)cnt) {
+            h.n_mm = p.n_mm; h.n_gapo = p.n_gapo; h.n_gape = p.n_gape;
+            h.ref_shift = (int)p.n_del - (int)p.n_ins; h.score = p.score;
+            x = lcg48_next(x); ++draws;
+            h.sa = p.k + (bwtint)((double)wdt * ((double)x * (1.0 / 281474976710656.0)));
+        }
+        cnt += (int)wdt;
+    }
+    h.c1 = cnt;
+    for (; i < na; ++i) cnt += (int)((unsigned long long)(al[i].l - al[i].k) + 1ull);
+    h.c2 = cnt - h.c1;
+    h.type = h.c1 > 1 ? 2 : 1;
+    return draws;
+}
+
 // the single-best reads: two draws at a stream position known from the prefix counts
 __global__ void k_select(SelectArgs a)
 {
@@ -678,19 +709,11 @@ __global__ void k_select(SelectArgs a)
             const unsigned int hb = a.h_before[g];
             const unsigned long long off = a.draws_in + 2ull * a.e_before[g] + (hb ? a.hard_cum[hb - 1] : 0ull);
             unsigned long long x = lcg_jump((11ull << 16) | 0x330Eull, off);
-            x = (x * 0x5DEECE66DULL + 0xBULL) & 0xFFFFFFFFFFFFULL;            // first draw: r*w > 0 unless the state is 0
-            if (x == 0) *a.err = 1;
-            x = (x * 0x5DEECE66DULL + 0xBULL) & 0xFFFFFFFFFFFFULL;            // second draw places the hit inside its interval
-            const AlnRec p = al[0];
-            const unsigned long long wdt = (unsigned long long)(p.l - p.k) + 1ull;
-            const double r2 = (double)x * (1.0 / 281474976710656.0);
-            s.sa = p.k + (bwtint)((double)wdt * r2);
-            int cnt = (int)wdt;
-            s.c1 = cnt;
-            for (int j = 1; j < na; ++j) cnt += (int)((unsigned long long)(al[j].l - al[j].k) + 1ull);
-            s.c2 = cnt - s.c1;
-            s.type = s.c1 > 1 ? 2 : 1;
-            s.n_mm = p.n_mm; s.n_gapo = p.n_gapo; s.n_gape = p.n_gape; s.ref_shift = (int8_t)((int)p.n_del - (int)p.n_ins); s.score = (uint8_t)p.score;
+            if (lcg48_next(x) == 0) *a.err = 1;       // the offsets assume two draws per such read: the first draw wins unless it is exactly 0
+            MainPick pk;
+            (void)rule_choose_main(al, na, x, pk);
+            s.sa = pk.sa; s.c1 = pk.c1; s.c2 = pk.c2; s.type = (uint8_t)pk.type;
+            s.n_mm = (uint8_t)pk.n_mm; s.n_gapo = (uint8_t)pk.n_gapo; s.n_gape = (uint8_t)pk.n_gape; s.ref_shift = (int8_t)pk.ref_shift; s.score = (uint8_t)pk.score;
         }
         a.sel[g] = s;
         a.rows[g] = s.type ? s.sa : 0;
@@ -943,25 +966,12 @@ const AlnRec *Batch::alns_of(int64_t g, int &n)
 // draws from ONE drand48 stream (seed 11) over all reads in input order.
 static int choose_main(const AlnRec *al, int na, Rng48 &rng, Hit &h)
 {
-    int cnt = 0, draws = 0, i;
-    const int best = al[0].score;
-    for (i = 0; i < na; ++i) {
-        const AlnRec &p = al[i];
-        if (p.score > best) break;
-        const uint64_t wdt = (uint64_t)(p.l - p.k) + 1ull;
-        ++draws;
-        if (rng.drand() * (double)(wdt + (uint64_t)(int64_t)cnt) > (double)cnt) {
-            h.n_mm = p.n_mm; h.n_gapo = p.n_gapo; h.n_gape = p.n_gape;
-            h.ref_shift = (int)p.n_del - (int)p.n_ins; h.score = p.score;
-            h.sa = p.k + (bwtint)((double)wdt * rng.drand());
-            ++draws;
-        }
-        cnt += (int)wdt;
-    }
-    h.c1 = cnt;
-    for (; i < na; ++i) cnt += (int)((uint64_t)(al[i].l - al[i].k) + 1ull);
-    h.c2 = cnt - h.c1;
-    h.type = h.c1 > 1 ? 2 : 1;
+    MainPick pk;
+    unsigned long long x = rng.x;
+    const int draws = rule_choose_main(al, na, x, pk);
+    rng.x = x;
+    h.sa = pk.sa; h.c1 = pk.c1; h.c2 = pk.c2; h.type = pk.type;
+    h.n_mm = pk.n_mm; h.n_gapo = pk.n_gapo; h.n_gape = pk.n_gape; h.ref_shift = pk.ref_shift; h.score = pk.score;
     return draws;
 }
 
