@@ -4,9 +4,9 @@
 Builds the synthetic genome and index of bench.py once, then runs the search stage under a list of settings
 and prints one JSON line per setting (kernel ms from HIP events, counters, overflow counts).
 
-  python tools/ktune.py --genome-mbp 3100 --reads 10000000 --pool 512,1024,2048,16384 --variant 0,1
-Settings: --pool = tier-1 stack entries per lane (ps_ctx_set_tiers), --variant = PS_BT_VARIANT values
-(read by the library at every launch), --blocks = grid of the search kernel (0 = default).
+  python tools/ktune.py --genome-mbp 3100 --reads 10000000 --pool 512,1024,2048,16384 --env "PS_JUMP=0|1"
+Settings: --pool = tier-1 stack entries per lane (ps_ctx_set_tiers), --blocks = grid of the search kernel (0 = default),
+--env NAME=v1|v2,... = values of the library's PS_* knobs (read at every launch); PARASUITE_LIB=<path> runs another build.
 """
 import argparse
 import json
