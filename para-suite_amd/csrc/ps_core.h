@@ -465,7 +465,7 @@ PS_COLD void bt_hit(const BtArgs &a, BtLane &L, BtMem &m)
     if (L.n_aln == 0) {
         L.best_score = L.score;
         int t = L.units + md.u_tight;
-        L.max_units = t > md.max_units ? md.max_units : t;
+        L.max_units = t > L.max_units ? L.max_units : t;     // L.max_units: still the read's own budget before the first hit
     }
     if (L.score == L.best_score) L.best_cnt += (unsigned long long)(L.l - L.k) + 1ull;
     else if (L.best_cnt > (unsigned long long)md.max_top2) { bt_finish_read(a, L); return; }
@@ -536,11 +536,12 @@ PS_COLD bool bt_fetch(const BtArgs &a, BtLane &L, BtMem &m, int fetch_r)
             else m.rn[p] = w;
             nNu += (int)ps_popc(w) * (int)(md.u_mm_pk[4] & 0xffu);
         }
-        if (nNu > md.max_units) { bt_finish_read(a, L); return false; }
+        const int own_units = (a.lens && a.units_by_len) ? (int)a.units_by_len[len] : md.max_units;     // the read's own budget (md: the longest read's)
+        if (nNu > own_units) { bt_finish_read(a, L); return false; }
         L.k = 0; L.l = a.ix.seq_len; L.i = len; L.score = 0; L.units = 0;
         L.n_mm = L.n_gapo = L.n_gape = L.n_ins = L.n_del = 0; L.state = ST_M; L.ldp = 0;
         L.have_cur = true; L.n_stack = 0; L.bm0 = L.bm1 = 0; L.bump = 0; L.free_head = PS_NIL; L.cap = a.pool_cap; L.n_phantom = 0;
-        L.best_score = 1 << 29; L.max_units = md.max_units; L.best_cnt = 0;
+        L.best_score = 1 << 29; L.max_units = own_units; L.best_cnt = 0;
         return true;
 }
 

@@ -214,7 +214,8 @@ PS_COLD void nt_hit(const BtArgs &a, NLane &L, BtMem &m)
     const int n_aln = nl_n_aln(L.ctl);
     if (n_aln == 0) {
         int t = units + md.u_tight;
-        t = t > md.max_units ? md.max_units : t;
+        const int own = nl_max_units(L);             // still the read's own budget: nothing has tightened it before the first hit
+        t = t > own ? own : t;
         L.lim = (L.lim & 0x00FF0000u) | (uint32_t)score | ((uint32_t)t << 8);      // no best hit counted yet
     }
     if (score == nl_best_score(L)) {             // best_cnt is only ever compared with max_top2 (< 255 on the narrow tiers): kept saturating
@@ -267,7 +268,9 @@ PS_COLD bool nt_fetch(const BtArgs &a, NLane &L, BtMem &m, int r)
     const int len = a.lens ? a.lens[r] : a.len;
     L.r = r;
     L.ctl = (uint32_t)M_FETCH;                           // status RS_OK, no hit, no current entry, on the private stack slice
-    L.lim = 0xffu | ((uint32_t)md.max_units << 8) | ((uint32_t)len << 16);
+    // the budget is the read's own (a launch holds reads of every length that shares the seed rule; md is the longest read's)
+    const int max_units = (a.lens && a.units_by_len) ? (int)a.units_by_len[len] : md.max_units;
+    L.lim = 0xffu | ((uint32_t)max_units << 8) | ((uint32_t)len << 16);
     {
         const int ncw = lm_ncw(len), ncsw = lm_ncsw(md.seed_len);
         uint32_t *cw32 = reinterpret_cast<uint32_t *>(m.cw), *csw32 = reinterpret_cast<uint32_t *>(m.csw);
@@ -285,7 +288,7 @@ PS_COLD bool nt_fetch(const BtArgs &a, NLane &L, BtMem &m, int r)
         else m.rn[p] = w;
         nNu += (int)ps_popc(w) * (int)(md.u_mm_pk[4] & 0xffu);
     }
-    if (nNu > md.max_units) { nt_finish_read(a, L); return false; }
+    if (nNu > max_units) { nt_finish_read(a, L); return false; }
     L.kr = 0; L.lr = (uint32_t)a.ix.seq_len; L.wa = (uint32_t)len; L.wb = NW_ROOT_C << 6;     // the root: i = len, state M, score 0
     L.ctl |= NL_HAVE_CUR;
     L.nsb = 0; L.bm0 = 0; L.fh = 0xffffu; L.n_phantom = 0;

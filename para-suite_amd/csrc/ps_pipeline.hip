@@ -385,7 +385,11 @@ std::unique_ptr<Batch> batch_prepare(Ctx *ctx, ReadSet &&rs_in, int threads)
         if (it == class_of_len.end()) {
             Model md; std::string err;
             if (!make_model(ctx->opt, len, md, err)) throw Error(err);
-            const std::vector<int> key = {md.max_units, md.max_gapo, md.use_seed, md.seed_len, md.n_buckets, lm_nmask_in_regs(len) ? 1 : 0, (len + 15) / 16};
+            // What a launch needs to be uniform in: the seed rule and the gap limit.  The difference budget, the number of score buckets,
+            // the packed word count and where the N mask lives follow the read (budget: BtArgs::units_by_len) or the longest read of
+            // the bin (local-memory layout), so that adapter-trimmed input with dozens of lengths is ONE launch where it used to be
+            // one per budget step -- every launch ends with ~0.2 s of emptying machine
+            const std::vector<int> key = {md.max_gapo, md.use_seed, md.seed_len};
             auto bc = bin_of_class.find(key);
             if (bc == bin_of_class.end()) { bc = bin_of_class.emplace(key, (int)b->bins.size()).first; b->bins.emplace_back(); }
             it = class_of_len.emplace(len, bc->second).first;
@@ -549,6 +553,13 @@ static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases
     PS_HIP(hipMemsetAsync(queue, 0, 64, s));
     BtArgs a; std::memset(&a, 0, sizeof a);
     a.ix = ctx->ix.view; a.md = md; a.n_reads = n; a.len = len; a.lens = d_lens; a.n_lanes = n_lanes;
+    if (d_lens) {                                               // ragged launch: every read's own budget, by its length
+        uint8_t *tab = wk->pin_get<uint8_t>("units_by_len_h", 256);
+        for (int l2 = 0; l2 < 256; ++l2) { const int u = budget_diffs(ctx->opt, l2) * (ctx->opt.profile ? ctx->opt.unit : 1); tab[l2] = (uint8_t)(u > 255 ? 255 : u); }
+        uint8_t *d_tab = wk->ws_get<uint8_t>("units_by_len", 256);
+        PS_HIP(hipMemcpyAsync(d_tab, tab, 256, hipMemcpyHostToDevice, s));
+        a.units_by_len = d_tab;
+    }
     a.bases = d_bases; a.nmask = d_nmask; a.n_bw = (len + 15) / 16; a.n_mw = (len + 31) / 32;
     a.w = w; a.cwb = cwb; a.cswb = cswb;
     a.alns = alns; a.aln_cap = aln_cap; a.n_aln = n_aln; a.status = status;
@@ -724,6 +735,7 @@ struct PostArgs {
     const int32_t *ids; int n, len; const int32_t *lens; long long l_pac;
     const uint8_t *cls; const SelRec *sel; const bwtint *pos; FinRec *fin;
     int budget, profile, unit; const uint8_t *logn;     // MAPQ rule inputs; logn[n] = (int)(4.343 ln n + .5)
+    const uint8_t *budget_by_len;                        // with lens: the difference budget of a read of every length (budget: the longest read's)
     RefineItem *items; int32_t *item_g; unsigned int *n_items;
 };
 // ---- the two samse rules every finished hit goes through, ONE copy for the device kernel and for the host-finished subset ----
@@ -768,7 +780,8 @@ __global__ void k_post(PostArgs a)
             const int ref_len = (a.lens ? a.lens[r] : a.len) + s.ref_shift;
             int strand = 0;
             const long long p = rule_to_forward((long long)a.pos[g], a.l_pac, ref_len, strand);
-            const int mq = rule_mapq(s.c1, s.c2, s.n_mm, (int)s.score, a.budget, a.profile != 0, a.unit, a.logn);
+            const int budget = (a.lens && a.budget_by_len) ? (int)a.budget_by_len[a.lens[r]] : a.budget;
+            const int mq = rule_mapq(s.c1, s.c2, s.n_mm, (int)s.score, budget, a.profile != 0, a.unit, a.logn);
             f.pos = p; f.strand = (uint8_t)strand; f.mapq = (uint8_t)mq; f.type = p < 0 ? 0 : s.type;
             if (f.type != 0 && s.n_gapo) {
                 const unsigned int q = atomicAdd(a.n_items, 1u);
@@ -1130,6 +1143,10 @@ void batch_locate(Batch &b)
     mapq_logn_table(logn);
     uint8_t *d_logn = wk->ws_get<uint8_t>("logn", 256);
     PS_HIP(hipMemcpyAsync(d_logn, logn, 256, hipMemcpyHostToDevice, s));
+    uint8_t *h_budget = wk->pin_get<uint8_t>("budget_by_len_h", 256);
+    for (int l2 = 0; l2 < 256; ++l2) { const int bd = budget_diffs(ctx->opt, l2); h_budget[l2] = (uint8_t)(bd > 255 ? 255 : bd); }
+    uint8_t *d_budget = wk->ws_get<uint8_t>("budget_by_len", 256);
+    PS_HIP(hipMemcpyAsync(d_budget, h_budget, 256, hipMemcpyHostToDevice, s));
     b.dev_cigars.clear();
     struct BinItems { RefineItem *d_items; int32_t *d_item_g; unsigned int *d_n; unsigned int n; };
     std::vector<BinItems> bi_items(b.bins.size());
@@ -1142,7 +1159,7 @@ void batch_locate(Batch &b)
         PS_HIP(hipMemsetAsync(it.d_n, 0, 16, s));
         PostArgs a;
         a.ids = bin.d_ids.p; a.n = n; a.len = bin.len; a.lens = bin.ragged ? bin.d_lens.p : nullptr; a.l_pac = l_pac; a.cls = b.d_class.p; a.sel = b.d_sel.p; a.pos = b.d_pos.p; a.fin = b.d_fin.p;
-        a.budget = budget_diffs(ctx->opt, bin.len); a.profile = ctx->opt.profile; a.unit = ctx->opt.unit; a.logn = d_logn;
+        a.budget = budget_diffs(ctx->opt, bin.len); a.profile = ctx->opt.profile; a.unit = ctx->opt.unit; a.logn = d_logn; a.budget_by_len = d_budget;
         a.items = it.d_items; a.item_g = it.d_item_g; a.n_items = it.d_n;
         hipLaunchKernelGGL(k_post, dim3(std::min((n + 255) / 256, 4096)), dim3(256), 0, s, a);
         PS_HIP(hipMemcpyAsync(&it.n, it.d_n, 4, hipMemcpyDeviceToHost, s));

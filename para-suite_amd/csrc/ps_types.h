@@ -92,6 +92,7 @@ struct BtArgs {
     Model md;
     int n_reads, len, n_lanes;                        // len: the longest read of the launch (layout); lens: every read's own
     const int32_t *lens;                              // nullptr: all reads have length len
+    const uint8_t *units_by_len;                      // with lens: the difference budget (in units) of a read of every length 0..255; md.max_units is that of the longest
     // reads: 2-bit bases [w][n_reads] (base j of a read: word j>>4, bits 2*(j&15)), N mask [j>>5][n_reads]
     const uint32_t *bases; const uint32_t *nmask; int n_bw, n_mw;
     // from the width kernel, [pos][n_reads]: interval sizes w (updated by hit shadowing), compact
