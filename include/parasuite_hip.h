@@ -104,7 +104,7 @@ int     ps_batch_n_aln(ps_batch *, int32_t *out, int64_t cap);       /* per read
 int64_t ps_batch_alns(ps_batch *, int64_t read, ps_aln *out, int64_t cap);
 int     ps_batch_hits(ps_batch *, ps_hit *out, int64_t cap);
 int     ps_batch_timing(ps_batch *, ps_timing *out);
-int64_t ps_ctx_read_iters(ps_ctx *, uint32_t *out, int64_t cap);   /* profiling aid (env PS_READ_ITERS=1): per read of the last search launch two words -- iterations, stack slots used; returns the word count */
+int64_t ps_ctx_read_iters(ps_ctx *, uint32_t *out, int64_t cap);   /* profiling aid (env PS_READ_ITERS=1): per read of the last search launch 20 words -- iterations | stack slots used | lower bounds as fetched (read, seed << 8) and the effort estimate's two scans (<< 16, << 24) | best score, final budget << 8, hits << 16 | 16 words of D bounds -- in the order the launch held the reads (leading-base order of the bin, not input order); returns the word count */
 int     ps_batch_kstats(ps_batch *, int which /*0 width 1 backtrack 2 sa2pos*/, ps_kstats *out);
 /* host-only check of the read parser: whole file on `threads` threads (chunk_bytes 0) or streamed in windows of chunk_bytes as
  * ps_map does; out = {reads, bases, order-sensitive hash of names / sequences / qualities, pieces} */

@@ -1087,6 +1087,7 @@ static read_t *load_reads(const char *path, int64_t *n_out)
         }
     }
     free(buf);
+    if (!R) R = (read_t *)calloc(1, sizeof(read_t));   /* an input without reads is not an error: upstream prints the header and stops */
     *n_out = cnt;
     return R;
 }

@@ -232,7 +232,11 @@ class Ctx:
         blk = self.fetch(0).view("<u4").reshape(-1, 16)
         return self.bwt_syms_chunked(), blk[:, :4]
 
+    RI_WORDS = 20          # ps_types.h: PS_RI_WORDS
+
     def read_iters(self):
+        """per-read profile of the last search launch (PS_READ_ITERS=1), RI_WORDS words per read in the launch's own order of the reads:
+        iterations | stack slots | D(read), D(seed) << 8, the estimate's two scans << 16 / << 24 | best score, final budget << 8, hits << 16 | 16 words of D bounds"""
         n = lib().ps_ctx_read_iters(self.h, None, 0)
         out = np.zeros(n, dtype=np.uint32)
         lib().ps_ctx_read_iters(self.h, out.ctypes.data, n)

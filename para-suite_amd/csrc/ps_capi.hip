@@ -336,6 +336,7 @@ int ps_batch_kstats(ps_batch *b, int which, ps_kstats *o)
 // input order (only the reads whose draw count is data dependent sit on that chain), so the SAM does not depend on the cut,
 // on the number of workers or on the number of devices.  A finished piece gives its device memory back at once and at most
 // a few finished pieces wait for the writer: memory does not grow with the input.
+static const char *const PS_PG_LINE = "@PG\tID:parasuite-hip\tPN:parasuite-hip\tVN:0.1";
 namespace {
 struct ProfileSink { int min_mapq = 0, max_len = 0; std::string prefix; };    // ps_map_profiled: the first pass also counts its error profile
 }
@@ -440,7 +441,7 @@ static int map_core(int threads, const char *mm, const char *error_profile, cons
                         b = std::move(it->second); done.erase(it);
                     }
                     const auto t0 = std::chrono::steady_clock::now();
-                    batch_write_sam(*b, out_sam, first, "@PG\tID:parasuite-hip\tPN:parasuite-hip\tVN:0.1", nthr, !first);
+                    batch_write_sam(*b, out_sam, first, PS_PG_LINE, nthr, !first);
                     t_write += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
                     if (sink) {                                        // the same records, straight from memory, into the profile histograms
                         const auto tp = std::chrono::steady_clock::now();
@@ -457,10 +458,13 @@ static int map_core(int threads, const char *mm, const char *error_profile, cons
                     b.reset();                                         // pinned record buffers, the reads: released here, not on the GPU worker's time
                     t_release += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
                 }
-                if (first) {                      // no reads at all: an empty file
+                if (first) {                      // no reads at all: the header alone, as upstream's samse prints it before its read loop
+                    { std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return failed || index_state[0] == 1; }); if (failed) return; }
+                    const std::string h = sam_header(xs[0]->c.ix.ref, PS_PG_LINE);
                     FILE *f = std::fopen(out_sam, "wb");
                     if (!f) throw Error(std::string("cannot write ") + out_sam);
-                    std::fclose(f);
+                    const bool ok = std::fwrite(h.data(), 1, h.size(), f) == h.size();
+                    if (std::fclose(f) != 0 || !ok) throw Error(std::string("short write on ") + out_sam);
                 }
                 if (sink) {
                     ProfileCounts pc;

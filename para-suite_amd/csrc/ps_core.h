@@ -454,7 +454,7 @@ PS_HD void bt_finish_read(const BtArgs &a, BtLane &L)
 {
     a.n_aln[L.r] = L.n_aln;
     a.status[L.r] = (uint8_t)L.status;
-    if (a.read_iters) a.read_iters[2 * (size_t)L.r] = L.st.iters - L.iters0;
+    if (a.read_iters) a.read_iters[PS_RI_WORDS * (size_t)L.r] = L.st.iters - L.iters0;
     L.mode = M_FETCH;
 }
 
@@ -514,7 +514,7 @@ PS_COLD void bt_hit(const BtArgs &a, BtLane &L, BtMem &m)
 PS_COLD bool bt_fetch(const BtArgs &a, BtLane &L, BtMem &m, int fetch_r)
 {
     const Model &md = a.md;
-        const int r = fetch_r;
+        const int r = a.order ? a.order[fetch_r] : fetch_r;
         const int len = a.lens ? a.lens[r] : a.len;
         L.len = len;
         L.r = r; L.status = RS_OK; L.n_aln = 0; L.iters0 = L.st.iters;

@@ -16,6 +16,20 @@ struct WidthArgs {
     KStats *stats;
 };
 
+// Effort estimate (scheduling only, never a result): a read's search effort follows the score of its best hit, which is unknown
+// before the search; two greedy scans (from either end of the read) give a cheap estimate of it -- k_effort, ps_kernels.hip
+struct EffortArgs {
+    IndexView ix;
+    int n_reads, len;
+    const int32_t *lens;
+    const uint32_t *bases; const uint32_t *nmask;
+    uint32_t s_pk[5];        // substitution costs as the search uses them (Model::s_mm_pk)
+    int c_restart;           // charged where a scan has to start a new piece
+    uint32_t w_pin;          // a substitution is tried where the interval is at most this wide (the scan has pinned the locus down)
+    uint8_t *est;            // out: estimated score of the best hit, clipped to 255
+    uint16_t *est_ab;        // optional (profiling): the two scans' totals, byte each
+};
+
 struct RefineItem { int32_t read; bwtint rb; int32_t ref_shift; int32_t strand; };
 struct RefineArgs {
     IndexView ix;
@@ -28,6 +42,7 @@ struct RefineArgs {
 };
 
 void launch_width(const WidthArgs &a, hipStream_t s);
+void launch_effort(const EffortArgs &a, hipStream_t s);
 // false: model outside the packed ranges.  stats: the narrow tiers' kernel with per-lane counters (KStats, read_iters); the timed kernel carries none
 // fills the jump table of an index (ps_core.h): `levels` levels, jump_words(levels) words at `table`
 void launch_jump_build(const IndexView &ix, uint32_t *table, int levels, hipStream_t s);

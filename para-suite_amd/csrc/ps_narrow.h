@@ -262,9 +262,10 @@ PS_COLD void nt_hit(const BtArgs &a, NLane &L, BtMem &m)
 }
 
 // load one read into the lane's local memory and reset the search state; false if the read is rejected outright
-PS_COLD bool nt_fetch(const BtArgs &a, NLane &L, BtMem &m, int r)
+PS_COLD bool nt_fetch(const BtArgs &a, NLane &L, BtMem &m, int q)
 {
     const Model &md = a.md;
+    const int r = a.order ? a.order[q] : q;            // queue position -> read (the launch's hand-out order)
     const int len = a.lens ? a.lens[r] : a.len;
     L.r = r;
     L.ctl = (uint32_t)M_FETCH;                           // status RS_OK, no hit, no current entry, on the private stack slice

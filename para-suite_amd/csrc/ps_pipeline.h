@@ -87,7 +87,7 @@ struct Ctx {
     uint32_t pool_cap[3] = {16384, 65535, 2000064};   // stack entries per lane: 16-byte narrow tiers, then the wide tier
     int aln_cap[3] = {8, 256, 65536};
     bool want_kstats = false;      // search kernel with counters (KStats of the backtracking stage): measurement runs only
-    bool want_read_iters = false; std::vector<uint32_t> read_iters;   // profiling aid: last launch's per-read profile (iterations, stack slots), two words per read
+    bool want_read_iters = false; std::vector<uint32_t> read_iters;   // profiling aid: last launch's per-read profile (ps_types.h: BtArgs::read_iters), PS_RI_WORDS words per read, in the order the launch held the reads (a bin's leading-base order)
     int n_big = 4096;              // 1 MB stack slots a launch may hand to reads that outgrow their private slice
     int fetch_min = 8, hit_min = 1;    // batching hits costs more in idle lanes than it saves (measured)
     int host_threads = 8;
@@ -152,6 +152,7 @@ void batch_select_hard(Batch &b, uint64_t draws_before, uint64_t *draws_after);
 void batch_select_easy(Batch &b, int threads);
 void reserve_search_workspace(Ctx *ctx, int work_index);        // the big device allocations of a lane of work, ahead of its first search
 void batch_locate(Batch &b);                                    // SA walk kernel, strand / MAPQ, banded DP of gapped hits
+std::string sam_header(const RefSeq &ref, const char *pg_line);      // @SQ lines in FASTA order + the @PG line
 void batch_write_sam(Batch &b, const char *path, bool header, const char *pg_line, int threads, bool append = false);
 // the located hits with MAPQ >= min_mapq as records for the error-profile kernel (what the MAPQ-filtered BAM of the first pass holds:
 // PARAsuiteMapping.java:124-133 -> ErrorProfiling.java:145-172), appended to `out`; host memory only

@@ -488,6 +488,15 @@ __global__ void k_clip_counts(const int32_t *n_aln, int aln_cap, int n, uint32_t
     for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) { int m = n_aln[r]; out[r] = (uint32_t)(m > aln_cap ? aln_cap : (m < 0 ? 0 : m)); }
 }
 
+// hand-out order of a search launch: queue position -> read, heaviest estimated search first, the given (leading-base) order inside a class
+__global__ void k_order_keys(const uint8_t *est, int n, int cap, uint8_t *key, int32_t *iota)
+{
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+        const int e = est[r] > cap ? cap : est[r];
+        key[r] = (uint8_t)(cap - e); iota[r] = r;
+    }
+}
+
 struct EvTimer {
     hipEvent_t a, b; hipStream_t s;
     explicit EvTimer(hipStream_t st) : s(st) { PS_HIP(hipEventCreate(&a)); PS_HIP(hipEventCreate(&b)); PS_HIP(hipEventRecord(a, s)); }
@@ -530,6 +539,41 @@ static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases
     wa.ix = ctx->ix.view; wa.n_reads = n; wa.len = len; wa.lens = d_lens; wa.seed_len = seed_len; wa.use_seed = md.use_seed;
     wa.bases = d_bases; wa.nmask = d_nmask; wa.w = w; wa.cwb = cwb; wa.cswb = cswb; wa.stats = b.d_stats.p + 0;
     { EvTimer t(s); launch_width(wa, s); PS_HIP(hipGetLastError()); b.tm.ms_width += t.stop(); ++b.tm.n_width_launches; }
+    // ---- hand-out order: the reads with the heaviest estimated search first (k_effort), so that the launch does not end on them.
+    // PS_ORDER=0 switches it off (A/B runs).
+    const int32_t *d_order = nullptr; const uint8_t *d_est = nullptr; const uint16_t *d_est_ab = nullptr;
+    {
+        const char *eo = std::getenv("PS_ORDER");
+        const int mode = eo ? std::atoi(eo) : 1;
+        if (mode > 0 && n >= 4096) {
+            EvTimer t(s);
+            uint8_t *est = wk->ws_get<uint8_t>("est", (size_t)n), *key = wk->ws_get<uint8_t>("okey", (size_t)n), *key2 = wk->ws_get<uint8_t>("okey2", (size_t)n);
+            int32_t *iota = wk->ws_get<int32_t>("oiota", (size_t)n), *order = wk->ws_get<int32_t>("order", (size_t)n);
+            EffortArgs ea;
+            ea.ix = ctx->ix.view; ea.n_reads = n; ea.len = len; ea.lens = d_lens; ea.bases = d_bases; ea.nmask = d_nmask; ea.est = est;
+            int csum = 0;
+            for (int c = 0; c < 5; ++c) ea.s_pk[c] = md.s_mm_pk[c];
+            for (int sc = 0; sc < 4; ++sc) for (int tc = 0; tc < 4; ++tc) if (sc != tc) csum += md.s_mm[sc][tc];
+            ea.c_restart = std::max(1, (csum + 6) / 12);                      // an average mismatch
+            if (const char *e = std::getenv("PS_ORDER_RESTART")) ea.c_restart = std::max(1, std::atoi(e));
+            ea.w_pin = 16;
+            if (const char *e = std::getenv("PS_ORDER_WPIN")) ea.w_pin = (uint32_t)std::max(1, std::atoi(e));
+            ea.est_ab = ctx->want_read_iters ? wk->ws_get<uint16_t>("est_ab", (size_t)n) : nullptr;
+            launch_effort(ea, s);
+            d_est_ab = ea.est_ab;
+            int cap = 255;
+            if (const char *e = std::getenv("PS_ORDER_CAP")) cap = std::max(1, std::min(255, std::atoi(e)));
+            int bits = 1; while ((1 << bits) <= cap) ++bits;
+            hipLaunchKernelGGL(k_order_keys, dim3(std::min((n + 255) / 256, 4096)), dim3(256), 0, s, est, n, cap, key, iota);
+            size_t tb = 0;
+            PS_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, key, key2, iota, order, n, 0, bits, s));
+            uint8_t *tmp = wk->ws_get<uint8_t>("order_tmp", tb ? tb : 1);
+            PS_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tb, key, key2, iota, order, n, 0, bits, s));
+            PS_HIP(hipGetLastError());
+            b.tm.ms_width += t.stop();                                        // reported with the width stage: both prepare the search
+            d_order = order; d_est = est;
+        }
+    }
     int dev_cus = 256;
     { hipDeviceProp_t p; if (hipGetDeviceProperties(&p, ctx->device) == hipSuccess && p.multiProcessorCount > 0) dev_cus = p.multiProcessorCount; }
     // narrow entries link with 16-bit indices, keep one 64-bit bucket bitmap and count inserted / deleted bases in 3 bits each
@@ -565,6 +609,7 @@ static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases
     a.alns = alns; a.aln_cap = aln_cap; a.n_aln = n_aln; a.status = status;
     a.pool = pool; a.pool_cap = pool_cap; a.heads = heads; a.wide = wide ? 1 : 0; a.stats = b.d_stats.p + 1;
     a.queue = queue; a.fetch_min = ctx->fetch_min; a.hit_min = ctx->hit_min;
+    a.order = wide ? nullptr : d_order; a.est = d_est; a.est_ab = d_est_ab;
     if (const char *e = std::getenv("PS_FETCH_MIN")) a.fetch_min = std::max(1, std::atoi(e));       // tuning: read at every launch
     if (const char *e = std::getenv("PS_HIT_MIN")) a.hit_min = std::max(1, std::atoi(e));
     if (!wide && pool_cap < 65535 && ctx->n_big > 0) {         // large slots for the reads that outgrow their private slice
@@ -575,14 +620,14 @@ static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases
         PS_HIP(hipMemsetAsync(a.big_busy, 0, (size_t)a.n_big * 4, s));
     }
     uint32_t *riters = nullptr;
-    if (ctx->want_read_iters) { riters = wk->ws_get<uint32_t>("riters", (size_t)n * 2); PS_HIP(hipMemsetAsync(riters, 0, (size_t)n * 8, s)); a.read_iters = riters; }
+    if (ctx->want_read_iters) { riters = wk->ws_get<uint32_t>("riters", (size_t)n * PS_RI_WORDS); PS_HIP(hipMemsetAsync(riters, 0, (size_t)n * PS_RI_WORDS * 4, s)); a.read_iters = riters; }
     { EvTimer t(s);
       if (!launch_backtrack(a, wk->ws_get<BtArgs>("btargs", 1), blocks, lm, s, ctx->want_kstats || ctx->want_read_iters)) throw Error("cost model outside the ranges the search kernel packs (gap/score fields must fit a byte)");
       PS_HIP(hipGetLastError());
       const double ms = t.stop(); b.tm.ms_backtrack += ms; ++b.tm.n_backtrack_launches;
       { double t0_ = 0, t1_ = 0; t.span(ctx->ref_event, t0_, t1_); if (b.tm.n_backtrack_launches == 1) b.tm.bt_begin_ms = t0_; b.tm.bt_end_ms = t1_; }
       if (std::getenv("PS_VERBOSE")) std::fprintf(stderr, "[parasuite-hip]   backtrack launch: %d reads x %d bp, stack %u%s, %d lanes, %.1f ms\n", n, len, pool_cap, wide ? " (wide)" : "", n_lanes, ms); }
-    if (ctx->want_read_iters) { ctx->read_iters.resize((size_t)n * 2); PS_HIP(hipMemcpyAsync(ctx->read_iters.data(), riters, (size_t)n * 8, hipMemcpyDeviceToHost, s)); PS_HIP(hipStreamSynchronize(s)); }
+    if (ctx->want_read_iters) { ctx->read_iters.resize((size_t)n * PS_RI_WORDS); PS_HIP(hipMemcpyAsync(ctx->read_iters.data(), riters, (size_t)n * PS_RI_WORDS * 4, hipMemcpyDeviceToHost, s)); PS_HIP(hipStreamSynchronize(s)); }
 }
 
 // ------------------------------------------------------------- host helpers ------
@@ -1469,6 +1514,16 @@ void batch_profile_records(const Batch &b, int min_mapq, int threads, ProfRecord
     });
 }
 
+// @SQ per reference sequence in FASTA order, then our @PG: what upstream's samse prints before the first record -- also when
+// there is no record at all (bwa_print_sam_SQ runs before the read loop)
+std::string sam_header(const RefSeq &ref, const char *pg_line)
+{
+    std::string h;
+    for (const Contig &c : ref.contigs) { h += "@SQ\tSN:"; h += c.name; h += "\tLN:"; put_int(h, c.len); h.push_back('\n'); }
+    if (pg_line && pg_line[0]) { h += pg_line; h += "\n"; }
+    return h;
+}
+
 void batch_write_sam(Batch &b, const char *path, bool header, const char *pg_line, int threads, bool append)
 {
     if (!b.located) throw Error("write_sam before locate");
@@ -1482,9 +1537,7 @@ void batch_write_sam(Batch &b, const char *path, bool header, const char *pg_lin
         return true;
     };
     if (header) {
-        std::string h; char line[512];
-        for (const Contig &c : b.ctx->ix.ref.contigs) { std::snprintf(line, sizeof line, "@SQ\tSN:%s\tLN:%d\n", c.name.c_str(), c.len); h += line; }
-        if (pg_line && pg_line[0]) { h += pg_line; h += "\n"; }
+        const std::string h = sam_header(b.ctx->ix.ref, pg_line);
         if (!put(h.data(), h.size(), at)) throw Error(std::string("short write on ") + path);
         at += (off_t)h.size();
     }

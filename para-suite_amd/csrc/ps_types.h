@@ -86,6 +86,7 @@ struct KStats {            // per-launch counters (roofline accounting)
     unsigned long long occ_pairs, occ_same_blk, nodes, pushes, pops, lf_steps, iters, exact_steps;
 };
 
+static const int PS_RI_WORDS = 20;                     // words per read of the optional per-read profile (BtArgs::read_iters)
 // per-batch device state of the backtracking stage (all SoA over reads, or per lane)
 struct BtArgs {
     IndexView ix;
@@ -109,7 +110,10 @@ struct BtArgs {
     // stay valid), released when the read is done
     uint8_t *big_pool; uint32_t big_cap, n_big; uint32_t *big_busy; uint32_t *big_next;
     uint32_t *queue;                                  // next unassigned read (waves take chunks of it)
-    uint32_t *read_iters;                             // optional per-read profile, two words per read: iterations spent, stack slots used (narrow tiers' counting kernel)
+    const int32_t *order;                             // optional: the read at every queue position (heaviest estimated search first, ps_pipeline.hip run_search); nullptr: position == read
+    const uint8_t *est; const uint16_t *est_ab;       // optional (profiling): the effort estimate the order was made from; its two scans
+    uint32_t *read_iters;                             // optional per-read profile (narrow tiers' counting kernel), PS_RI_WORDS words per read: iterations spent | stack slots used |
+                                                      // D bound of the whole read, of the seed <<8, the estimate's two scans <<16, <<24 | best score, final budget <<8, hits <<16 | 16 words: the D bounds
     int hit_min;                                      // lanes with a pending hit a wave collects before it records them
     int fetch_min;                                    // idle lanes a wave waits for before it loads new reads
     KStats *stats;

@@ -330,6 +330,33 @@ def test_ps_map_streams_in_pieces(mid, workdir, monkeypatch, capfd):
     assert not bad, (len(bad), g[bad[0]], o[bad[0]])
 
 
+def test_ps_map_empty_fastq_writes_header(multi, workdir):
+    """an input without reads: upstream's samse prints the @SQ header before its read loop (oracle/ps_oracle.c: orc_map_fastq
+    does the same), so `samtools view -bS` (PARAsuiteMapping.java:103-110) still gets a valid SAM: ps_map must not leave 0 bytes"""
+    import capi
+    import orc
+    fa = multi["fa"]
+    if not os.path.exists(fa + ".bwt"):
+        capi.ps_index(fa)
+    for tag, text in (("empty", ""), ("blank", "\n\n")):
+        fq = os.path.join(workdir, "none_%s.fq" % tag)
+        open(fq, "w").write(text)
+        out, osam = os.path.join(workdir, "none_%s.sam" % tag), os.path.join(workdir, "none_%s.orc.sam" % tag)
+        capi.ps_map(4, "0.04", None, None, fa, fq, out)
+        multi["orc_index"].map_fastq(orc.stock_opt("0.04"), fq, osam, n_threads=2)
+        assert sam_records(out) == sam_records(osam) == []
+        assert sam_sq(out) == sam_sq(osam) and len(sam_sq(out)) == 3
+        assert [l.split("\t")[1] for l in sam_sq(out)] == ["SN:chrA", "SN:chrB", "SN:chrC"]         # FASTA order
+    # ... and through the argv shim, which is what the unmodified jar would run (PARAsuiteMapping.java:63-92)
+    import subprocess
+    bwa = os.path.join(os.path.dirname(capi.__file__), "bin", "bwa")
+    fq = os.path.join(workdir, "none_empty.fq")
+    sai, out = os.path.join(workdir, "none.sai"), os.path.join(workdir, "none_shim.sam")
+    subprocess.check_call([bwa, "aln", "-t", "2", "-n", "2", fa, fq, "-f", sai])
+    subprocess.check_call([bwa, "samse", fa, sai, fq, "-f", out])
+    assert sam_records(out) == [] and len(sam_sq(out)) == 3
+
+
 def test_ps_map_reports_errors_without_hanging(mid, workdir):
     """failures in the parser or the writer thread of ps_map come back as an error status (Mapping.executeCommand's
     contract: non-zero, message) -- and the other stages are released, no thread waits forever"""

@@ -17,7 +17,7 @@ for mode in ('stock', 'profile'):
         P = np.array(bench.PROFILE); P[3,1], P[3,3] = 0.12, 0.87
         ctx.set_profile(P, bench.INS_RATE, bench.DEL_RATE, -1)
     b = ctx.batch_from_codes(rd); b.search(); tm = b.timing()
-    it = ctx.read_iters().astype(np.int64)
+    it = ctx.read_iters().reshape(-1, capi.Ctx.RI_WORDS).astype(np.int64)[:, 0]
     q = np.percentile(it, [50, 90, 99, 99.9, 99.99, 99.999, 100]).astype(int)
     srt = np.sort(it)
     print(mode, n, 'bt ms %.1f' % tm['ms_backtrack'], 'iters mean %.0f' % it.mean(), 'pct 50/90/99/99.9/99.99/99.999/max', q.tolist(),

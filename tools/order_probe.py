@@ -32,7 +32,7 @@ ctx.set_profile(P, bench.INS_RATE, bench.DEL_RATE, -1)
 ctx.set_stats(True)
 b = ctx.batch_from_codes(rd)
 b.search()
-it = ctx.read_iters().reshape(-1, 2).astype(np.int64)[:, 0]
+it = ctx.read_iters().reshape(-1, capi.Ctx.RI_WORDS).astype(np.int64)[:, 0]
 print("iterations per read: mean %.0f, percentiles 50/90/99/99.9/max %s" % (it.mean(), np.percentile(it, [50, 90, 99, 99.9, 100]).astype(int).tolist()), flush=True)
 del b
 ctx.set_stats(False)

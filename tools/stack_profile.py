@@ -28,7 +28,7 @@ P = np.array(bench.PROFILE); P[3, 1], P[3, 3] = 0.12, 0.87
 ctx.set_profile(P, bench.INS_RATE, bench.DEL_RATE, -1)
 b = ctx.batch_from_codes(rd)
 b.search()
-prof = ctx.read_iters().reshape(-1, 2).astype(np.int64)
+prof = ctx.read_iters().reshape(-1, capi.Ctx.RI_WORDS).astype(np.int64)
 it, slots = prof[:, 0], prof[:, 1]
 print("reads %d: iterations mean %.0f; stack slots used per read: mean %.0f, percentiles 50/90/99/99.9/99.99/max %s" %
       (len(it), it.mean(), slots.mean(), np.percentile(slots, [50, 90, 99, 99.9, 99.99, 100]).astype(int).tolist()))
