@@ -7,9 +7,11 @@ packed and resident in HBM.  Workload at N=1: BASELINE.json configs[2] -- 10 M x
 PAR-CLIP reads, full difference-tolerant search + gapped extension -- against a synthetic genome of
 hg19's size (--genome-mbp, default 3100 in 24 contigs: 6.2e9 BWT rows, which is why rows are 33-bit;
 hg19 itself is not on the box and there is no network to fetch it).
-N>1: one process per GPU, the FM index built on rank 0 and broadcast once with RCCL, every rank maps
-its own --reads reads (weak scaling, no data-path collective); the only exchange is one integer per
-rank that chains the tie-break RNG stream in input order.
+N>1: one process per GPU, the FM index built on rank 0 and broadcast once with RCCL.  --scaling strong (the
+default, BASELINE.json configs[3]): the --reads reads are ONE job, rank r maps the contiguous range
+ceil(reads/N)*r .. (sharding.shard_range); --scaling weak: every rank maps its own --reads reads.  No
+data-path collective either way; the only exchange is one integer per rank that chains the tie-break RNG
+stream in input order.
 
 Launch:  python bench.py [--gpus 1] [--steps K] [--warmup W]
          python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -194,7 +196,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU")
+    ap.add_argument("--reads", type=int, default=10_000_000, help="reads of the job (--scaling strong: shared by the ranks; weak: per GPU)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong", help="N>1: strong = --reads in all, contiguous range per rank (BASELINE configs[3]); weak = --reads per GPU")
+    ap.add_argument("--drain", type=int, default=1, help="N=1: also time single launches of 1/8, 1/4, 1/2 of the batch (what a rank of a 8/4/2-GPU strong-scaling job would run)")
     ap.add_argument("--read-len", type=int, default=50)
     ap.add_argument("--genome-mbp", type=int, default=3100)
     ap.add_argument("--contigs", type=int, default=24)
@@ -289,15 +293,21 @@ def main():
         ctx.set_profile(P, INS_RATE, DEL_RATE, -1)
 
     t1 = time.time()
-    codes = gen_reads(torch, dev, contigs, args.reads, args.read_len, 0x5EED0003 + rank, indels=(args.workload == "full"))
+    strong = args.scaling == "strong"
+    if strong:          # one job: every rank generates the same reads (same seed) and keeps its contiguous range
+        lo, hi = sharding.shard_range(args.reads, rank, world)
+        codes = gen_reads(torch, dev, contigs, args.reads, args.read_len, 0x5EED0003, indels=(args.workload == "full"))[lo:hi]
+    else:
+        codes = gen_reads(torch, dev, contigs, args.reads, args.read_len, 0x5EED0003 + rank, indels=(args.workload == "full"))
+    n_mine = codes.shape[0]
     del contigs
     torch.cuda.empty_cache()
     # the batch of a step as S sub-batches (contiguous halves, input order) on S lanes: stream + workspace each
     ctx.set_lanes(S * PIPE)
-    cut = [args.reads * j // S for j in range(S + 1)]
+    cut = [n_mine * j // S for j in range(S + 1)]
     sets = [[ctx.batch_from_codes(codes[cut[j]:cut[j + 1]]) for j in range(S)] for _ in range(PIPE)]    # PIPE copies of the step's batch
     batches = sets[0]
-    log("%d reads generated, packed and uploaded as %d sub-batch(es), %d batch(es) in flight, in %.1fs" % (args.reads, S, PIPE, time.time() - t1))
+    log("%d reads (%s scaling: %d of the job's) generated, packed and uploaded as %d sub-batch(es), %d batch(es) in flight, in %.1fs" % (n_mine, args.scaling, args.reads if strong else world * args.reads, S, PIPE, time.time() - t1))
 
     chain = torch.zeros(1, dtype=torch.int64, device=dev if args.backend == "nccl" else "cpu")
     wall = {"search": 0.0, "select_hard": 0.0, "select_easy": 0.0, "locate": 0.0, "bt_union": 0.0}
@@ -476,6 +486,44 @@ def main():
         for b in batches:
             for k, v in b.kstats(2).items():
                 ks_sa[k] = ks_sa.get(k, 0) + v
+        # ---- the same steps one after the other (what --pipeline 1 times): nothing overlaps, so the HIP events around each
+        # launch are the kernel's own duration INSIDE a timed region; rocprofv3 --kernel-trace of `bench.py --pipeline 1` agrees
+        pipe1 = None
+        if PIPE > 1 and world == 1:
+            walls, kms = [], []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                for b in batches:
+                    b.run(threads)
+                torch.cuda.synchronize()
+                walls.append(1e3 * (time.perf_counter() - t2)); kms.append(sum(b.timing()["ms_backtrack"] for b in batches))
+            pipe1 = {"ms_per_step": sum(walls) / len(walls), "kernel_ms_per_step": sum(kms) / len(kms), "steps": len(walls),
+                     "reads_per_s": n_mine / (sum(walls) / len(walls) * 1e-3)}
+        # ---- launch drain (N=1): what a rank of a 2/4/8-GPU strong-scaling job would run -- the first 1/2, 1/4, 1/8 of the batch
+        # as ONE step each (search + samse stages), nothing else on the GPU.  Every search launch ends with its longest reads;
+        # T(n) is not proportional to n, and that -- not the index broadcast, not the chain -- is what bounds strong scaling.
+        drain = None
+        if world == 1 and args.drain and S == 1:
+            rows = []
+            for div in (8, 4, 2, 1):
+                nb = max(1, n_mine // div)
+                sb = batches[0] if div == 1 else ctx.batch_from_codes(codes[:nb])
+                w_, k_ = [], []
+                for _ in range(2):
+                    torch.cuda.synchronize()
+                    t2 = time.perf_counter()
+                    sb.run(threads)
+                    torch.cuda.synchronize()
+                    w_.append(1e3 * (time.perf_counter() - t2)); k_.append(sb.timing()["ms_backtrack"])
+                rows.append({"reads": nb, "ms_step": min(w_), "ms_backtrack": min(k_)})
+                if div != 1:
+                    sb.free()
+            full = rows[-1]["ms_step"]
+            drain = {"single_launch_steps": rows,
+                     "implied_speedup": {str(g): full / r["ms_step"] for g, r in zip((8, 4, 2), rows[:3])},
+                     "note": "one step (search + samse stages) over the first 1/8, 1/4, 1/2 and all of the batch, each alone on the GPU, best of two; "
+                             "implied_speedup[G] = T(all) / T(1/G): what G GPUs can reach on this job (--scaling strong) before any multi-GPU cost"}
         n_bt = max(1, acc["n_backtrack_launches"])
         ms_bt_sum_step = acc["ms_backtrack"] / K          # summed over the launches of a step (two lanes overlap in time)
         ms_bt_union_step = 1e3 * wall["bt_union"] / K       # first launch's start to last launch's end: the time the kernel had the GPU
@@ -494,17 +542,20 @@ def main():
         hits = np.concatenate([b.hits() for b in batches])
         res = {
             "metric": "aligned reads/sec (10Mx50bp PAR-CLIP vs hg19-size genome) on MI355X; SAM bit-exact vs own CPU restatement (parity unpinned)",
-            "value": world * args.reads * args.steps / elapsed,
+            "value": (args.reads if strong else world * args.reads) * args.steps / elapsed,
             "unit": "reads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / K,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "configs[2]: %dx%dbp simulated PAR-CLIP reads per GPU, %s, vs %d Mbp synthetic genome "
-                                   "(hg19-size synthetic genome; 33-bit BWT rows)" % (args.reads, args.read_len,
+            "config": {"workload": "%s: %dx%dbp simulated PAR-CLIP reads %s, %s, vs %d Mbp synthetic genome "
+                                   "(hg19-size synthetic genome; 33-bit BWT rows)" % (
+                                   "configs[2]" if world == 1 else ("configs[3]" if strong else "configs[2] per GPU"), args.reads, args.read_len,
+                                   "in all, contiguous ranges of ceil(reads/%d) per GPU" % world if strong else "per GPU",
                                    "error-profile seed + banded extension" if args.workload == "full" else "exact-match seed only",
                                    args.genome_mbp),
-                       "reads_per_gpu": args.reads, "read_len": args.read_len, "genome_mbp": args.genome_mbp,
+                       "reads_total": args.reads if strong else world * args.reads,
+                       "reads_per_gpu": -(-args.reads // world) if strong else args.reads, "read_len": args.read_len, "genome_mbp": args.genome_mbp,
                        "mode": args.workload, "penalty": args.penalty, "sub_batches": S, "pipeline": PIPE,
                        "parallelism": "reads sharded x%d, index replicated" % world},
             "value_scope": "search + samse stages on reads already packed in HBM -> per-read alignment records in pinned host memory "
@@ -533,7 +584,11 @@ def main():
                          "requested_bytes_note": "what the timed kernel asks the memory for in search steps: 64 B per distinct Occ block of the steps it takes through "
                                                  "the Occ array (its own two counters) + 32 B per step answered by the jump table (DESIGN.md section 2); the algorithmic "
                                                  "bytes above are those of the reference's algorithm, counted without the table",
-                         "width_kernel": {"achieved": alg_w / (ms_w_step * 1e-3) / 1e9, "frac": alg_w / (ms_w_step * 1e-3) / 1e9 / 8000.0}},
+                         "width_kernel": {"achieved": alg_w / (ms_w_step * 1e-3) / 1e9, "frac": alg_w / (ms_w_step * 1e-3) / 1e9 / 8000.0},
+                         "pipeline1": (dict(pipe1, achieved=alg_bt / (pipe1["kernel_ms_per_step"] * 1e-3) / 1e9,
+                                            frac=alg_bt / (pipe1["kernel_ms_per_step"] * 1e-3) / 1e9 / 8000.0,
+                                            note="the same batch, steps one after the other right after the timed region (what `bench.py --pipeline 1` times): "
+                                                 "HIP events around every launch, inside the region, nothing overlapping") if pipe1 and dominant_bt else None)},
             "kernels_ms_per_step": {k: acc[k] / K for k in ("ms_width", "ms_backtrack", "ms_select", "ms_sa2pos",
                                                             "ms_refine", "ms_host_post", "ms_classify", "ms_sel_hard", "ms_sel_easy")},
             "stage_wall_ms_per_step": {k: 1e3 * v / K for k, v in wall.items()},
@@ -543,6 +598,7 @@ def main():
             "kstats": {"backtrack": ks_bt, "width": ks_w, "sa2pos": ks_sa, "backtrack_timed_kernel": ks_timed},
             "mapped_frac": float((hits["type"] != 0).mean()),
             "overflow_reads": [int(acc["n_overflow_tier1"] / K), int(acc["n_overflow_tier2"] / K)],
+            "drain": drain,
         }
         # HBM traffic of the dominant kernel: PMC passes cannot run inside the timed job, so the committed passes of
         # the same configuration are quoted (profiles/pmc_traffic.json), null when none matches
@@ -633,12 +689,48 @@ def main():
                     t3 = time.perf_counter()
                     capi.ps_map(threads, mm, ep, ip, fa, fq_all, out_sam)
                     times.append(time.perf_counter() - t3)
-                res["t_e2e_s"] = min(times)
-                res["value_e2e"] = args.reads / min(times)
+                res["t_e2e_s"] = times[-1]                # a warm call: the process has mapped before (page-locked buffers, code objects)
+                res["t_e2e_first_call_s"] = times[0]      # the first call of this process
+                res["value_e2e"] = args.reads / times[-1]
                 res["e2e"] = {"scope": "one ps_map call: index files -> HBM, FASTQ file parsed, search + samse, SAM text written and closed "
                                        "(the scope of the reference's own timer, PARAsuiteMapping.java:57,94-97)",
                               "seconds_per_call": times, "fastq_bytes": os.path.getsize(fq_all), "sam_bytes": os.path.getsize(out_sam),
                               "host_threads": threads}
+                # ---- cold: what the UNMODIFIED jar's timer would show -- two fresh `bwa` processes per pass, exactly the argv of
+                # PARAsuiteMapping.java:63-77 / 85-92 (BWAMapping.java:51-75 for stock costs), through the argv shim.  New child
+                # processes (never a re-exec of this one); this process holds nothing on the GPU any more.
+                try:
+                    import hashlib
+                    import subprocess
+                    bwa = os.path.join(ROOT, "para-suite_amd", "bin", "bwa")
+                    sai, cold_sam = os.path.join(tmpdir, "reads.sai"), os.path.join(tmpdir, "reads.cold.sam")
+                    if ep:
+                        argv1 = [bwa, "parasuite", "-t", str(threads), "-X", mm, "-p", ep, "-g", ip, fa, fq_all, "-f", sai]
+                    else:
+                        argv1 = [bwa, "aln", "-t", str(threads), "-n", mm, fa, fq_all, "-f", sai]
+                    argv2 = [bwa, "samse", fa, sai, fq_all, "-f", cold_sam]
+                    t3 = time.perf_counter()
+                    subprocess.run(argv1, check=True, timeout=600)
+                    t4 = time.perf_counter()
+                    subprocess.run(argv2, check=True, timeout=600)
+                    t5 = time.perf_counter()
+
+                    def md5(path):
+                        h = hashlib.md5()
+                        with open(path, "rb") as f:
+                            for blk in iter(lambda: f.read(1 << 24), b""):
+                                h.update(blk)
+                        return h.hexdigest()
+                    res["t_e2e_cold_s"] = t5 - t3
+                    res["e2e"]["cold"] = {"seconds": {"bwa parasuite|aln": t4 - t3, "bwa samse": t5 - t4},
+                                          "argv": [" ".join(os.path.basename(a) if a.startswith("/") else a for a in v) for v in (argv1, argv2)],
+                                          "sam_md5": md5(cold_sam), "same_bytes_as_warm_call": md5(cold_sam) == md5(out_sam),
+                                          "note": "two child processes started one after the other as Mapping.executeCommand does (Mapping.java:151-198); "
+                                                  "each pays process start, HIP initialisation, the index load and every allocation"}
+                    os.remove(cold_sam)
+                except Exception as e:  # noqa: BLE001
+                    res["t_e2e_cold_s"] = None
+                    res["e2e"]["cold"] = {"failed": repr(e)}
                 for pth in (fq_all, out_sam):
                     os.remove(pth)
             except Exception as e:  # noqa: BLE001

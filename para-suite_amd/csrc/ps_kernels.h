@@ -25,9 +25,24 @@ struct EffortArgs {
     const uint32_t *bases; const uint32_t *nmask;
     uint32_t s_pk[5];        // substitution costs as the search uses them (Model::s_mm_pk)
     int c_restart;           // charged where a scan has to start a new piece
-    uint32_t w_pin;          // a substitution is tried where the interval is at most this wide (the scan has pinned the locus down)
+    uint32_t w_pin;          // a substitution is believed where the interval is at most this wide (the scan has pinned its locus down)
+    int c_indel;             // charged where a cluster of substitutions is taken for an indel
     uint8_t *est;            // out: estimated score of the best hit, clipped to 255
     uint16_t *est_ab;        // optional (profiling): the two scans' totals, byte each
+};
+
+// expected search nodes of a read from its estimated final budget and its D(i) bounds (ps_effort.hip); out: the sort key of the hand-out order
+struct EffortModelArgs {
+    int n_reads, len;
+    const int32_t *lens; const uint8_t *units_by_len;
+    const uint32_t *bases; const uint32_t *nmask; const uint32_t *cwb;
+    const uint8_t *est;
+    uint32_t s_pk[5]; uint32_t inv_c_min;
+    int max_units, u_tight, seed_units, use_seed, seed_len;
+    int depth;               // levels modelled (beyond ~19 symbols a random string no longer occurs in a genome of this size)
+    float rows;              // BWT rows: a string of d symbols has min(1, rows / 4^d) expected occurrences
+    int log_scale;           // key = 255 - log2(expected nodes) * log_scale
+    uint8_t *key; float *pred;      // pred: optional (profiling)
 };
 
 struct RefineItem { int32_t read; bwtint rb; int32_t ref_shift; int32_t strand; };
@@ -43,6 +58,7 @@ struct RefineArgs {
 
 void launch_width(const WidthArgs &a, hipStream_t s);
 void launch_effort(const EffortArgs &a, hipStream_t s);
+void launch_effort_model(const EffortModelArgs &a, hipStream_t s);
 // false: model outside the packed ranges.  stats: the narrow tiers' kernel with per-lane counters (KStats, read_iters); the timed kernel carries none
 // fills the jump table of an index (ps_core.h): `levels` levels, jump_words(levels) words at `table`
 void launch_jump_build(const IndexView &ix, uint32_t *table, int levels, hipStream_t s);

@@ -80,70 +80,6 @@ __global__ void __launch_bounds__(256) k_width(WidthArgs a)
     flush_stats(a.stats, st);
 }
 
-// ---- effort estimate: in which order the search launch hands its reads out ----
-// A read's search effort grows exponentially with the budget it ends up with, i.e. with the score of its best hit (mean iterations
-// 238 / 475 / 1,126 / 3,574 / 14,919 at final budgets 8 / 11 / 14 / 17 / 24; profiles/r03_order_probe.txt), and a launch that hands
-// its heaviest reads out LAST ends with ~0.2 s of emptying machine.  The best score is what the search computes -- but a greedy
-// scan guesses it well: extend the read exactly through the index; where the interval empties AND the scan has pinned the locus
-// down (interval at most w_pin rows), take the cheapest substitution that continues it, else start a new piece and charge an
-// average mismatch.  A difference inside the first ~16 bases of a piece is not seen where it is (the interval still holds random
-// matches), so the scan runs from both ends of the read (the index holds both strands: the reverse complement scanned backwards
-// is the read scanned forwards) and the smaller total counts.  Scheduling only: no result depends on it.
-struct EChain { bwtint k, l; uint32_t cost; int run; };      // run: bases matched exactly since the last substitution / restart
-__device__ __forceinline__ void echain_step(const EffortArgs &a, EChain &c, int sym, uint32_t cw, LaneStats &st)
-{
-    // sym: the symbol the pattern grows by (0..3, 4 = N); cw: cost of finding text symbol t there instead, byte t
-    if (sym > 3) { c.k = 0; c.l = a.ix.seq_len; c.cost += (uint32_t)a.c_restart; c.run = 0; return; }
-    uint32_t ck[4], cl[4];
-    occ_pair4(a.ix.blocks, a.ix.primary, c.k, c.l, ck, cl, st);
-    const uint32_t ok = sel4(ck, sym), ol = sel4(cl, sym);
-    if (ok < ol) { const bwtint b = L2_of(a.ix, sym); c.k = b + ok + 1; c.l = b + ol; ++c.run; return; }
-    int best = -1; uint32_t best_cost = 0xffu;
-    // a second difference right behind a substitution is more likely an indel (the read is shifted against the locus from there on:
-    // substitutions would be paid base after base): start a new piece instead
-    if (c.l - c.k < (bwtint)a.w_pin && c.run >= 4) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const uint32_t ct = (cw >> (8 * t)) & 0xffu;
-            if (t != sym && ck[t] < cl[t] && ct < best_cost) { best = t; best_cost = ct; }
-        }
-    }
-    if (best >= 0) { const bwtint b = L2_of(a.ix, best); c.k = b + sel4(ck, best) + 1; c.l = b + sel4(cl, best); c.cost += best_cost; }
-    else { c.k = 0; c.l = a.ix.seq_len; c.cost += (uint32_t)a.c_restart; }
-    c.run = 0;
-}
-__global__ void __launch_bounds__(256) k_effort(EffortArgs a)
-{
-    const int stride = gridDim.x * blockDim.x;
-    LaneStats st = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < a.n_reads; r += stride) {
-        const int len = a.lens ? a.lens[r] : a.len;
-        EChain A = {0, a.ix.seq_len, 0, 0}, B = {0, a.ix.seq_len, 0, 0};
-        uint32_t bwA = 0, mwA = 0, bwB = 0, mwB = 0;
-        for (int i = 0; i < len; ++i) {
-            // chain A: the read itself, grown leftwards from its last base; chain B: its reverse complement, i.e. the read from its first base
-            const int ja = len - 1 - i, jb = i;
-            if (i == 0 || (ja & 15) == 15) bwA = a.bases[(size_t)(ja >> 4) * a.n_reads + r];
-            if (i == 0 || (ja & 31) == 31) mwA = a.nmask[(size_t)(ja >> 5) * a.n_reads + r];
-            if ((jb & 15) == 0) bwB = a.bases[(size_t)(jb >> 4) * a.n_reads + r];
-            if ((jb & 31) == 0) mwB = a.nmask[(size_t)(jb >> 5) * a.n_reads + r];
-            const int ba = ((mwA >> (ja & 31)) & 1u) ? 4 : (int)((bwA >> (2 * (ja & 15))) & 3u);
-            const int bb = ((mwB >> (jb & 31)) & 1u) ? 4 : (int)((bwB >> (2 * (jb & 15))) & 3u);
-            // costs: the search consumes the reverse-complemented read (code s = 3 - base) against text symbol t: s_pk[s] byte t.
-            // Chain B is exactly that.  Chain A matches the other strand: base b against text t is code 3 - b against text 3 - t.
-            const int sb = bb > 3 ? 4 : 3 - bb;
-            const uint32_t cwB = cost_word(a.s_pk, sb);
-            const uint32_t wA = cost_word(a.s_pk, ba > 3 ? 4 : 3 - ba);
-            const uint32_t cwA = __builtin_bswap32(wA);            // byte t of cwA = byte 3 - t of wA
-            echain_step(a, A, ba, cwA, st);
-            echain_step(a, B, sb, cwB, st);
-        }
-        const uint32_t e = A.cost < B.cost ? A.cost : B.cost;
-        a.est[r] = (uint8_t)(e > 255u ? 255u : e);
-        if (a.est_ab) a.est_ab[r] = (uint16_t)((A.cost > 255u ? 255u : A.cost) | ((B.cost > 255u ? 255u : B.cost) << 8));
-    }
-}
-
 // ---- seed / backtracking stage --------------------------------------------
 // wave-uniform value pinned in a scalar register (a kernel argument would otherwise be re-read from memory
 // wherever the compiler runs short of registers -- inside the loop)
@@ -402,13 +338,6 @@ __global__ void __launch_bounds__(64) k_refine(RefineArgs a)
 }
 
 // ---- launch wrappers ---------------------------------------------------------
-void launch_effort(const EffortArgs &a, hipStream_t s)
-{
-    int blocks = (a.n_reads + 255) / 256;
-    if (blocks > 256 * 8) blocks = 256 * 8;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_effort, dim3(blocks), dim3(256), 0, s, a);
-}
 void launch_width(const WidthArgs &a, hipStream_t s)
 {
     int blocks = (a.n_reads + 255) / 256;

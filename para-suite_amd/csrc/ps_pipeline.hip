@@ -497,6 +497,8 @@ __global__ void k_order_keys(const uint8_t *est, int n, int cap, uint8_t *key, i
     }
 }
 
+__global__ void k_iota(int n, int32_t *iota) { for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) iota[r] = r; }
+
 struct EvTimer {
     hipEvent_t a, b; hipStream_t s;
     explicit EvTimer(hipStream_t st) : s(st) { PS_HIP(hipEventCreate(&a)); PS_HIP(hipEventCreate(&b)); PS_HIP(hipEventRecord(a, s)); }
@@ -539,8 +541,8 @@ static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases
     wa.ix = ctx->ix.view; wa.n_reads = n; wa.len = len; wa.lens = d_lens; wa.seed_len = seed_len; wa.use_seed = md.use_seed;
     wa.bases = d_bases; wa.nmask = d_nmask; wa.w = w; wa.cwb = cwb; wa.cswb = cswb; wa.stats = b.d_stats.p + 0;
     { EvTimer t(s); launch_width(wa, s); PS_HIP(hipGetLastError()); b.tm.ms_width += t.stop(); ++b.tm.n_width_launches; }
-    // ---- hand-out order: the reads with the heaviest estimated search first (k_effort), so that the launch does not end on them.
-    // PS_ORDER=0 switches it off (A/B runs).
+    // ---- hand-out order: the reads with the heaviest predicted search first (ps_effort.hip), so that the launch does not end on
+    // them.  PS_ORDER=0 switches it off, 2 orders by the estimated best score alone (A/B runs).
     const int32_t *d_order = nullptr; const uint8_t *d_est = nullptr; const uint16_t *d_est_ab = nullptr;
     {
         const char *eo = std::getenv("PS_ORDER");
@@ -558,13 +560,36 @@ static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases
             if (const char *e = std::getenv("PS_ORDER_RESTART")) ea.c_restart = std::max(1, std::atoi(e));
             ea.w_pin = 16;
             if (const char *e = std::getenv("PS_ORDER_WPIN")) ea.w_pin = (uint32_t)std::max(1, std::atoi(e));
+            ea.c_indel = std::max(ea.c_restart, std::min(md.s_gapo_ins, md.s_gapo_del));
+            int lv = 0; while (lv < 31 && (ctx->ix.view.seq_len >> (2 * lv)) > 0) ++lv;              // 4^lv > rows: 17 at hg19 size
             ea.est_ab = ctx->want_read_iters ? wk->ws_get<uint16_t>("est_ab", (size_t)n) : nullptr;
             launch_effort(ea, s);
             d_est_ab = ea.est_ab;
-            int cap = 255;
-            if (const char *e = std::getenv("PS_ORDER_CAP")) cap = std::max(1, std::min(255, std::atoi(e)));
-            int bits = 1; while ((1 << bits) <= cap) ++bits;
-            hipLaunchKernelGGL(k_order_keys, dim3(std::min((n + 255) / 256, 4096)), dim3(256), 0, s, est, n, cap, key, iota);
+            int bits = 8;
+            if (mode == 2) {
+                int cap = 255;
+                if (const char *e = std::getenv("PS_ORDER_CAP")) cap = std::max(1, std::min(255, std::atoi(e)));
+                bits = 1; while ((1 << bits) <= cap) ++bits;
+                hipLaunchKernelGGL(k_order_keys, dim3(std::min((n + 255) / 256, 4096)), dim3(256), 0, s, est, n, cap, key, iota);
+            } else {
+                EffortModelArgs em;
+                em.n_reads = n; em.len = len; em.lens = d_lens; em.units_by_len = nullptr; em.bases = d_bases; em.nmask = d_nmask; em.cwb = cwb; em.est = est;
+                for (int c = 0; c < 5; ++c) em.s_pk[c] = md.s_mm_pk[c];
+                em.inv_c_min = (uint32_t)md.inv_c_min; em.max_units = md.max_units; em.u_tight = md.u_tight;
+                em.seed_units = md.max_seed_diff * md.u_tight; em.use_seed = md.use_seed; em.seed_len = md.seed_len;
+                em.depth = lv + 3; em.rows = (float)ctx->ix.view.seq_len; em.log_scale = 8;
+                if (const char *e = std::getenv("PS_ORDER_SCALE")) em.log_scale = std::max(1, std::min(12, std::atoi(e)));
+                if (d_lens) {                                             // ragged launch: every read's own budget, by its length
+                    uint8_t *tab = wk->pin_get<uint8_t>("units_by_len_h2", 256);
+                    for (int l2 = 0; l2 < 256; ++l2) { const int u = budget_diffs(ctx->opt, l2) * (ctx->opt.profile ? ctx->opt.unit : 1); tab[l2] = (uint8_t)(u > 255 ? 255 : u); }
+                    uint8_t *d_tab = wk->ws_get<uint8_t>("units_by_len2", 256);
+                    PS_HIP(hipMemcpyAsync(d_tab, tab, 256, hipMemcpyHostToDevice, s));
+                    em.units_by_len = d_tab;
+                }
+                em.key = key; em.pred = nullptr;
+                launch_effort_model(em, s);
+                hipLaunchKernelGGL(k_iota, dim3(std::min((n + 255) / 256, 4096)), dim3(256), 0, s, n, iota);
+            }
             size_t tb = 0;
             PS_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, key, key2, iota, order, n, 0, bits, s));
             uint8_t *tmp = wk->ws_get<uint8_t>("order_tmp", tb ? tb : 1);

@@ -12,12 +12,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("mode", ["sub_batches", "pipeline"])
+@pytest.mark.parametrize("mode", ["sub_batches", "pipeline", "strong"])
 def test_two_ranks_bench_rehearsal(tmp_path, mode):
     """two bench.py ranks (gloo, both on GPU 0) with the tie-break stream chained through the ranks -- "sub_batches": each rank maps
     its shard as two overlapping sub-batches (the chain also runs through them); "pipeline": the default, consecutive steps
-    alternate between two batches in flight and take the chain in step order.  The per-read records of both ranks,
-    concatenated, equal those of ONE process mapping the same reads as one batch.  (RCCL / xGMI itself cannot run on the
+    alternate between two batches in flight and take the chain in step order; "strong": BASELINE configs[3]'s shape -- ONE job of
+    --reads reads, rank r maps the contiguous range sharding.shard_range gives it (the default of bench.py for N > 1; the
+    other two modes are --scaling weak: --reads per rank).  The per-read records of both ranks, concatenated, equal those of ONE
+    process mapping the same reads as one batch.  (RCCL / xGMI itself cannot run on the
     one-GPU test box: no N > 1 hardware number exists.)"""
     import numpy as np
     import torch
@@ -28,14 +30,18 @@ def test_two_ranks_bench_rehearsal(tmp_path, mode):
     dump = str(tmp_path / "hits")
     mbp, n_reads = 8, 60000
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29655" if mode == "sub_batches" else "29657", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu",
-           "--genome-mbp", str(mbp), "--contigs", "4", "--reads", str(n_reads), "--cpu-sample", "0", "--dump-hits", dump]
+           "--master-port", {"sub_batches": "29655", "pipeline": "29657", "strong": "29659"}[mode], os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu",
+           "--genome-mbp", str(mbp), "--contigs", "4", "--reads", str(n_reads if mode != "strong" else 2 * n_reads + 1), "--cpu-sample", "0", "--dump-hits", dump]
+    cmd += ["--scaling", "strong" if mode == "strong" else "weak"]
     cmd += ["--steps", "1", "--warmup", "1", "--sub-batches", "2"] if mode == "sub_batches" else ["--steps", "4", "--warmup", "1"]
     r = subprocess.run(cmd, env=env, timeout=900, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.split("\n") if l.startswith("{")][-1]
     d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["n_gpus"] == 2 and d["scaling"] == ("strong" if mode == "strong" else "weak") and d["value"] > 0
+    total = 2 * n_reads + 1 if mode == "strong" else 2 * n_reads           # strong: an odd total, so the ranges differ in size
+    assert d["config"]["reads_total"] == total and d["config"]["reads_per_gpu"] == -(-total // 2 if mode == "strong" else -n_reads)
+    assert abs(d["value"] - total * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]      # whole-job reads over the slowest rank's time
     assert (d["config"]["sub_batches"], d["config"]["pipeline"]) == ((2, 1) if mode == "sub_batches" else (1, 2))
     assert d["mapped_frac"] > 0.8
     got = np.concatenate([np.load(os.path.join(dump, "hits_rank%d.npy" % k)) for k in range(2)])
@@ -47,11 +53,14 @@ def test_two_ranks_bench_rehearsal(tmp_path, mode):
     ctx = capi.Ctx.build(fa, device=0)
     P = np.array(B.PROFILE); P[3, 1], P[3, 3] = 0.12, 0.87
     ctx.set_profile(P, B.INS_RATE, B.DEL_RATE, -1)
-    codes = np.concatenate([B.gen_reads(torch, dev, contigs, n_reads, 50, 0x5EED0003 + k) for k in range(2)])
+    if mode == "strong":
+        codes = B.gen_reads(torch, dev, contigs, total, 50, 0x5EED0003)
+    else:
+        codes = np.concatenate([B.gen_reads(torch, dev, contigs, n_reads, 50, 0x5EED0003 + k) for k in range(2)])
     one = ctx.batch_from_codes(codes)
     one.run(8)
     exp = one.hits()
-    assert len(got) == len(exp) == 2 * n_reads
+    assert len(got) == len(exp) == total
     for f in ("pos", "sa", "type", "strand", "mapq", "n_mm", "n_gapo", "c1", "c2", "n_cigar", "n_multi"):
         assert np.array_equal(got[f], exp[f]), f
     assert (exp["c1"] > 1).sum() > 100       # reads that did need the random tie-break, on both sides of every hand-over

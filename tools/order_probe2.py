@@ -115,10 +115,14 @@ def classes_then_lib(cls):                  # heaviest class (largest value) fir
 
 # the library orders by leading bases itself (PS_KEEP_ORDER unset); PS_ORDER = its own effort order on top
 timed(None, "product, PS_ORDER=0", env={"PS_ORDER": "0"})
-timed(None, "product, PS_ORDER=1 (est order, defaults)", env={"PS_ORDER": "1"})
-timed(None, "PS_ORDER=1 cap 16", env={"PS_ORDER": "1", "PS_ORDER_CAP": "16"})
+timed(None, "PS_ORDER=1 (expected-nodes model, defaults)", env={"PS_ORDER": "1"})
+timed(None, "PS_ORDER=1 scale 4", env={"PS_ORDER": "1", "PS_ORDER_SCALE": "4"})
+timed(None, "PS_ORDER=1 scale 2", env={"PS_ORDER": "1", "PS_ORDER_SCALE": "2"})
+timed(None, "PS_ORDER=2 (estimated score only) cap 16", env={"PS_ORDER": "2", "PS_ORDER_CAP": "16"})
+timed(None, "product, PS_ORDER=0 again", env={"PS_ORDER": "0"})
 os.environ["PS_KEEP_ORDER"] = "1"          # from here on the library keeps the order it is given
 os.environ["PS_ORDER"] = "0"
 timed(classes_then_lib(budget1), "oracle: classes by TRUE final budget")
 q = np.searchsorted(np.quantile(it, np.arange(1, 8) / 8), it, side="right")
 timed(classes_then_lib(q), "oracle-8 (true counts, classes)")
+timed(np.argsort(-it, kind="stable"), "oracle-sort (longest first, no locality)")
