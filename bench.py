@@ -73,6 +73,79 @@ def gen_genome(torch, dev, total_bp, n_contigs, seed):
     return out
 
 
+def add_repeats(torch, dev, contigs, seed, share=0.45, info=None):
+    """Repeat structure of a mammalian genome on top of gen_genome's text (bench.py --genome-profile repeats): interspersed
+    families -- 300-bp units (SINE-like: one family with a copy per ~2.6 kb, minor ones with 10^3-10^5 copies at full scale)
+    and 6-kb units (LINE-like, most copies truncated at their 5' end) -- every copy 2-20 % diverged from its family's consensus
+    and on either strand; microsatellites (1-6 bp motifs, 10-60 units); a few satellite arrays (171-bp unit in tandem, 1-2 %
+    diverged).  `share` of the bases end up inside interspersed copies (hg19: ~45 %).  Copy numbers scale with the genome so
+    that a small test genome has the same density.  Deterministic in (seed, sizes); the N runs of gen_genome are restored.
+    info (a dict, optional) receives where the satellite arrays went: info["satellites"] = [(contig index, start, length)]."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    total = sum(c.numel() for _, c in contigs)
+    fam = []                                   # (unit length, share of the genome, divergence range, truncated copies)
+    fam.append((300, 0.115, (0.05, 0.18), False))
+    for k in range(6):
+        fam.append((300, 0.012, (0.02 + 0.02 * k, 0.06 + 0.025 * k), False))
+    for k in range(5):
+        fam.append((6000, 0.045, (0.02 + 0.03 * k, 0.08 + 0.03 * k), True))
+    scale = share / sum(f[1] for f in fam) / 0.80          # later copies overwrite earlier ones: ~20 % of the placed bases are lost
+    cons = [torch.randint(0, 4, (u,), generator=g, device=dev, dtype=torch.uint8) for u, _, _, _ in fam]
+    comp = torch.tensor([3, 2, 1, 0], dtype=torch.uint8, device=dev)
+    for ci, (name, codes) in enumerate(contigs):
+        n = codes.numel()
+        if n < 20000:
+            continue
+        holes = codes == 4
+        for (u, sh, (d0, d1), trunc), cs in zip(fam, cons):
+            copies = int(n * sh * scale / (u * (0.55 if trunc else 1.0)))
+            step = max(1, (1 << 22) // u)
+            for a0 in range(0, copies, step):
+                m = min(step, copies - a0)
+                dst = (torch.rand(m, generator=g, device=dev, dtype=torch.float64) * (n - u - 1)).long()
+                div = d0 + (d1 - d0) * torch.rand(m, generator=g, device=dev)
+                piece = cs[None, :].expand(m, u)
+                mut = torch.rand((m, u), generator=g, device=dev) < div[:, None]
+                piece = torch.where(mut, (piece + torch.randint(1, 4, (m, u), generator=g, device=dev, dtype=torch.uint8)) & 3, piece)
+                rev = torch.rand(m, generator=g, device=dev) < 0.5
+                piece = torch.where(rev[:, None], comp[piece.flip(1).long()], piece)
+                ar = torch.arange(u, device=dev, dtype=torch.int64)[None, :]
+                if trunc:                                    # keep the last `keep` bases of the unit (5'-truncated insertions)
+                    keep = (u * (0.1 + 0.9 * torch.rand(m, generator=g, device=dev) ** 2)).long().clamp_(50, u)
+                    ok = ar >= (u - keep)[:, None]
+                    idx = (dst[:, None] + ar)[ok]
+                    codes[idx] = piece[ok]
+                else:
+                    codes[(dst[:, None] + ar).reshape(-1)] = piece.reshape(-1)
+        # microsatellites: one per ~15 kb
+        k = max(1, n // 15000)
+        for a0 in range(0, k, 4096):
+            m = min(4096, k - a0)
+            mot_len = torch.randint(1, 7, (m,), generator=g, device=dev)
+            units = torch.randint(10, 61, (m,), generator=g, device=dev)
+            motif = torch.randint(0, 4, (m, 6), generator=g, device=dev, dtype=torch.uint8)
+            ar = torch.arange(360, device=dev, dtype=torch.int64)[None, :]
+            seq = torch.gather(motif, 1, ar % mot_len[:, None])
+            ok = ar < (mot_len * units)[:, None]
+            dst = (torch.rand(m, generator=g, device=dev, dtype=torch.float64) * (n - 361)).long()
+            codes[(dst[:, None] + ar)[ok]] = seq[ok]
+        # satellite arrays: ~0.3 % of the contig in arrays of 171-bp units
+        n_arr = max(1, int(n * 0.003) // (171 * 400))
+        for _ in range(n_arr):
+            unit = torch.randint(0, 4, (171,), generator=g, device=dev, dtype=torch.uint8)
+            reps = 400
+            arr = unit.repeat(reps)
+            mut = torch.rand(arr.numel(), generator=g, device=dev) < 0.015
+            arr = torch.where(mut, (arr + torch.randint(1, 4, (arr.numel(),), generator=g, device=dev, dtype=torch.uint8)) & 3, arr)
+            at = int(torch.rand(1, generator=g, device=dev).item() * (n - arr.numel() - 1))
+            codes[at:at + arr.numel()] = arr
+            if info is not None:
+                info.setdefault("satellites", []).append((ci, at, int(arr.numel())))
+        codes[holes] = 4
+    return contigs
+
+
 def write_fasta(path, contigs, width=50):
     lut = np.frombuffer(b"ACGTN", dtype=np.uint8)
     with open(path, "wb") as f:
@@ -202,6 +275,9 @@ def main():
     ap.add_argument("--read-len", type=int, default=50)
     ap.add_argument("--genome-mbp", type=int, default=3100)
     ap.add_argument("--contigs", type=int, default=24)
+    ap.add_argument("--genome-profile", choices=["default", "repeats"], default="default",
+                    help="repeats: ~45 %% of the genome in interspersed repeat families (300-bp and 6-kb units, 2-20 %% diverged), microsatellites and "
+                         "satellite arrays (add_repeats) instead of an i.i.d. text with 4 %% two-copy segments")
     ap.add_argument("--workload", choices=["full", "exact"], default="full")
     ap.add_argument("--cpu-sample", type=int, default=250000, help="reads of the same workload timed on the CPU oracle (0 = skip)")
     ap.add_argument("--threads", type=int, default=0)
@@ -246,6 +322,8 @@ def main():
     # ---------------- data: genome on every rank (same seed), index built on rank 0 ----------------
     t0 = time.time()
     contigs = gen_genome(torch, dev, args.genome_mbp * 1_000_000, args.contigs, 0x5EED0002)
+    if args.genome_profile == "repeats":
+        contigs = add_repeats(torch, dev, contigs, 0x5EED0009)
     tmpdir = args.keep or tempfile.mkdtemp(prefix="psbench_")
     os.makedirs(tmpdir, exist_ok=True)
     fa = os.path.join(tmpdir, "genome.fa")
@@ -556,6 +634,7 @@ def main():
                                    args.genome_mbp),
                        "reads_total": args.reads if strong else world * args.reads,
                        "reads_per_gpu": -(-args.reads // world) if strong else args.reads, "read_len": args.read_len, "genome_mbp": args.genome_mbp,
+                       "genome_profile": args.genome_profile,
                        "mode": args.workload, "penalty": args.penalty, "sub_batches": S, "pipeline": PIPE,
                        "parallelism": "reads sharded x%d, index replicated" % world},
             "value_scope": "search + samse stages on reads already packed in HBM -> per-read alignment records in pinned host memory "
@@ -597,6 +676,7 @@ def main():
                                        "roofline.avg_launch_ms") if PIPE > 1 else None,
             "kstats": {"backtrack": ks_bt, "width": ks_w, "sa2pos": ks_sa, "backtrack_timed_kernel": ks_timed},
             "mapped_frac": float((hits["type"] != 0).mean()),
+            "x0_gt1_frac": float((hits["c1"] > 1).mean()), "x0_gt30_frac": float((hits["c1"] > 30).mean()),
             "overflow_reads": [int(acc["n_overflow_tier1"] / K), int(acc["n_overflow_tier2"] / K)],
             "drain": drain,
         }

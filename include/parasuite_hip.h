@@ -73,6 +73,7 @@ int64_t ps_ctx_meta(ps_ctx *, char *buf, int64_t cap);               /* serialis
 ps_ctx *ps_ctx_from_blobs(const char *meta, int64_t meta_len, int device, void *const dev_ptrs[3]); /* borrowed device memory */
 int     ps_ctx_fetch(ps_ctx *, int which, void *host_dst, uint64_t bytes); /* D2H copy of a blob (tests) */
 int     ps_ctx_export_blob(ps_ctx *, int which, void *dev_dst, uint64_t bytes); /* D2D copy into caller memory (broadcast source) */
+int     ps_ctx_index_check(ps_ctx *, uint64_t out[4]);   /* every row of the index checked against the packed text along the LF cycle: rows visited (== seq_len + 1), BWT symbol mismatches, SA sample mismatches, longest arc */
 int     ps_ctx_sa_lookup(ps_ctx *, const uint64_t *rows, int64_t n, uint64_t *out); /* SA[row], rows in [1, seq_len]: index checks from the text */
 
 ps_batch *ps_batch_from_fastq(ps_ctx *, const char *fastq);

@@ -44,7 +44,8 @@ class Hit(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("occ_pairs", C.c_uint64), ("occ_same_blk", C.c_uint64), ("nodes", C.c_uint64),
-                ("pushes", C.c_uint64), ("lf_steps", C.c_uint64), ("max_stack", C.c_uint64)]
+                ("pushes", C.c_uint64), ("lf_steps", C.c_uint64), ("max_stack", C.c_uint64),
+                ("top2_breaks", C.c_uint64), ("max_entries_stops", C.c_uint64)]
 
 
 class Rng(C.Structure):

@@ -313,6 +313,7 @@ static void stats_flush(void)
     {
         g_st_total.occ_pairs += g_st.occ_pairs; g_st_total.occ_same_blk += g_st.occ_same_blk;
         g_st_total.nodes += g_st.nodes; g_st_total.pushes += g_st.pushes; g_st_total.lf_steps += g_st.lf_steps;
+        g_st_total.top2_breaks += g_st.top2_breaks; g_st_total.max_entries_stops += g_st.max_entries_stops;
         if (g_st.max_stack > g_st_total.max_stack) g_st_total.max_stack = g_st.max_stack;
     }
     memset(&g_st, 0, sizeof g_st);
@@ -612,7 +613,7 @@ static int match_gap(const orc_index_t *ix, int len, const uint8_t *seq, orc_wid
     while (h.n_entries) {
         entry_t e; int i, m, m_seed = 0, hit, allow_diff, allow_M, tmp, rem;
         uint64_t k, l, ck[4], cl[4], occ;
-        if (h.n_entries > o->max_entries) break;
+        if (h.n_entries > o->max_entries) { ++g_st.max_entries_stops; break; }
         heap_pop(&h, &e);
         k = e.k; l = e.l; i = e.i;
         if (e.score > best_score + md->s_stop) break;
@@ -634,7 +635,7 @@ static int match_gap(const orc_index_t *ix, int len, const uint8_t *seq, orc_wid
                 max_units = e.units + md->u_tight > md->max_units ? md->max_units : e.units + md->u_tight;
             }
             if (e.score == best_score) best_cnt += l - k + 1;
-            else if (best_cnt > (uint64_t)o->max_top2) break;
+            else if (best_cnt > (uint64_t)o->max_top2) { ++g_st.top2_breaks; break; }
             if (e.n_gapo) {
                 int t, lim = n_aln < cap ? n_aln : cap;
                 for (t = 0; t < lim; ++t) if (out[t].k == k && out[t].l == l) break;

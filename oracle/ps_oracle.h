@@ -79,6 +79,8 @@ typedef struct {            /* instrumentation for roofline accounting */
     uint64_t pushes;
     uint64_t lf_steps;       /* SA-walk steps                               */
     uint64_t max_stack;
+    uint64_t top2_breaks;    /* searches ended by the -R rule (a worse hit arrives with > max_top2 best ones) */
+    uint64_t max_entries_stops; /* searches ended by the -m rule                      */
 } orc_stats_t;
 
 void     orc_default_opt(orc_opt_t *o);

@@ -41,7 +41,7 @@ HIT_DTYPE = np.dtype([("pos", "<i8"), ("sa", "<u8"), ("type", "<i4"), ("strand",
 
 EXPORTS = ["ps_version", "ps_last_error", "ps_index", "ps_map", "ps_ctx_open", "ps_ctx_build", "ps_ctx_close",
            "ps_ctx_set_stock", "ps_ctx_set_profile", "ps_ctx_set_profile_matrix", "ps_ctx_set_tiers", "ps_ctx_set_stats", "ps_ctx_set_lanes", "ps_ctx_info",
-           "ps_ctx_blob", "ps_ctx_meta", "ps_ctx_from_blobs", "ps_ctx_fetch", "ps_ctx_export_blob", "ps_ctx_sa_lookup", "ps_sam_to_bam", "ps_bam_view", "ps_bam_sort", "ps_bam_index", "ps_batch_from_fastq",
+           "ps_ctx_blob", "ps_ctx_meta", "ps_ctx_from_blobs", "ps_ctx_fetch", "ps_ctx_export_blob", "ps_ctx_sa_lookup", "ps_ctx_index_check", "ps_sam_to_bam", "ps_bam_view", "ps_bam_sort", "ps_bam_index", "ps_batch_from_fastq",
            "ps_batch_from_codes", "ps_batch_free", "ps_batch_n", "ps_batch_search", "ps_batch_select_hard",
            "ps_batch_select_easy", "ps_batch_locate", "ps_batch_run", "ps_batch_write_sam", "ps_batch_n_aln",
            "ps_batch_alns", "ps_batch_hits", "ps_batch_timing", "ps_batch_kstats", "ps_ctx_read_iters", "ps_parse_check", "ps_error_profile", "ps_map_profiled", "ps_release_host_cache"]
@@ -81,6 +81,7 @@ def lib():
     L.ps_ctx_fetch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]
     L.ps_ctx_export_blob.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]
     L.ps_ctx_sa_lookup.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    L.ps_ctx_index_check.argtypes = [C.c_void_p, C.c_void_p]
     L.ps_batch_from_fastq.argtypes = [C.c_void_p, C.c_char_p]
     L.ps_batch_from_fastq.restype = C.c_void_p
     L.ps_batch_from_codes.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
@@ -204,6 +205,12 @@ class Ctx:
         out |= hi.reshape(-1)[:n_sa].astype(np.uint64) << np.uint64(32)
         out[0] = np.uint64(0xFFFFFFFFFFFFFFFF)
         return out
+
+    def index_check(self):
+        """every row of the index against the packed text along the LF cycle -> dict(rows, bad_symbols, bad_samples, longest_arc)"""
+        out = np.zeros(4, dtype=np.uint64)
+        _chk(lib().ps_ctx_index_check(self.h, out.ctypes.data))
+        return dict(rows=int(out[0]), bad_symbols=int(out[1]), bad_samples=int(out[2]), longest_arc=int(out[3]))
 
     def sa_lookup(self, rows):
         """SA[row] for rows in [1, seq_len] (device LF walk to a sampled row)"""

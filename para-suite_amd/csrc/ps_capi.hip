@@ -114,6 +114,24 @@ int ps_ctx_set_profile(ps_ctx *x, const char *ep, const char *ip, const char *x_
     PS_CATCH_INT
 }
 // SA[row] for arbitrary rows of the BW matrix (LF walk to a sampled row: the kernel the samse stage uses): index checks
+// every row of the index against the text (ps_kernels.hip: k_index_check): out = rows visited (must be seq_len + 1), BWT symbols that differ
+// from the text, SA samples that differ from the position counted along the LF cycle, longest arc between two samples
+int ps_ctx_index_check(ps_ctx *x, uint64_t out[4])
+{
+    PS_TRY
+        Ctx &c = x->c;
+        require_device(c.device);
+        DevBuf<unsigned long long> d; d.alloc(4);
+        PS_HIP(hipMemsetAsync(d.p, 0, 32, c.stream));
+        launch_index_check(c.ix.view, d.p, c.stream);
+        PS_HIP(hipGetLastError());
+        unsigned long long h[4];
+        d.download(h, 4, c.stream);
+        PS_HIP(hipStreamSynchronize(c.stream));
+        for (int j = 0; j < 4; ++j) out[j] = h[j];
+        return 0;
+    PS_CATCH_INT
+}
 int ps_ctx_sa_lookup(ps_ctx *x, const uint64_t *rows, int64_t n, uint64_t *out)
 {
     PS_TRY

@@ -279,6 +279,7 @@ struct BtHot {
     uint32_t s_pk[5], u_pk[5];       // substitution costs, one word per read symbol (byte c = text symbol)
     uint32_t p0, p1, p2, p3;
     uint32_t inv_c_min, max_entries, pool_cap, n_reads, big_cap;
+    uint32_t c_min;                  // the cheapest difference, in units
     PS_HD int len() const { return (int)(p0 & 0xffu); }
     PS_HD int seed_len() const { return (int)((p0 >> 8) & 0xffu); }
     PS_HD int indel_end_skip() const { return (int)((p0 >> 16) & 0xffu); }
@@ -325,6 +326,7 @@ inline bool bt_hot_make(const BtArgs &a, BtHot &h)
            ((md.profile ? 1u : 0u) << 10) | ((a.n_big ? 1u : 0u) << 11) | ((uint32_t)seed_units << 12) | ((uint32_t)md.u_tight << 24);
     h.p2 = (uint32_t)md.s_gapo_ins | ((uint32_t)md.s_gape << 8) | ((uint32_t)md.s_gapo_del << 16) | ((uint32_t)md.s_stop << 24);
     h.p3 = (uint32_t)md.u_gapo_ins | ((uint32_t)md.u_gape << 8) | ((uint32_t)md.u_gapo_del << 16) | ((uint32_t)md.n_buckets << 24);
+    h.c_min = (uint32_t)md.c_min;
     h.inv_c_min = (uint32_t)md.inv_c_min; h.max_entries = (uint32_t)md.max_entries; h.pool_cap = a.pool_cap; h.n_reads = (uint32_t)a.n_reads; h.big_cap = a.big_cap;
     return ok;
 }

@@ -99,6 +99,7 @@ __device__ __forceinline__ void pin_hot(BtHot &h, const BtHot &k)
 #pragma unroll
     for (int c = 0; c < 5; ++c) { h.s_pk[c] = pin32(k.s_pk[c]); h.u_pk[c] = pin32(k.u_pk[c]); }
     h.p0 = pin32(k.p0); h.p1 = pin32(k.p1); h.p2 = pin32(k.p2); h.p3 = pin32(k.p3);
+    h.c_min = pin32(k.c_min);
     h.inv_c_min = pin32(k.inv_c_min); h.max_entries = pin32(k.max_entries); h.pool_cap = pin32(k.pool_cap); h.n_reads = pin32(k.n_reads); h.big_cap = pin32(k.big_cap);
 }
 
@@ -309,6 +310,57 @@ __global__ void __launch_bounds__(256) k_sa2pos(IndexView ix, const bwtint *rows
         }
     }
     flush_stats(stats, st);
+}
+
+// ---- exhaustive self-check of an index against its text (ps_ctx_index_check) ----
+// The rows of the BW matrix form ONE cycle under LF, and walking it spells the text backwards.  Cut at the sampled rows it falls into
+// n_sa independent arcs: a thread starts at a sampled row r with p = SA[r], and until it reaches the next sampled row it checks, row by
+// row, that the BWT symbol there is T[p - 1] (T = forward strand + reverse complement, read from the packed text, NOT from the BWT) and
+// steps row = LF(row), p = p - 1; at the sampled row it arrives at, the stored sample must be the p it has counted down to.  Every row
+// lies on exactly one arc, so: symbol mismatches == 0, sample mismatches == 0 and rows visited == n + 1 together say that the last
+// column is the BWT of this text, that Occ / L2 (which LF is made of) are consistent with it, and that every SA sample is right.
+__device__ __forceinline__ int text_sym(const IndexView &ix, bwtint p) { return p < ix.l_pac ? pac_base(ix.pac, p) : 3 - pac_base(ix.pac, 2 * ix.l_pac - 1 - p); }
+__global__ void __launch_bounds__(256) k_index_check(IndexView ix, unsigned long long *out)
+{
+    unsigned long long rows = 0, bad_sym = 0, bad_sa = 0, longest = 0;
+    const bwtint n_sa = ix.n_sa;
+    for (bwtint t = (bwtint)blockIdx.x * blockDim.x + threadIdx.x; t < n_sa; t += (bwtint)gridDim.x * blockDim.x) {
+        bwtint row = t * (bwtint)ix.sa_intv;
+        bwtint p = t == 0 ? ix.seq_len : sa_sample(ix, t);        // row 0 is the empty suffix (stored as -1)
+        unsigned long long steps = 0;
+        do {
+            if (p == 0) {                                           // the whole text: its row holds '$' in the last column
+                if (row != ix.primary) ++bad_sym;
+                row = 0; p = ix.seq_len;
+            } else {
+                if (row == ix.primary) { ++bad_sym; break; }
+                int pos = 0;
+                const uint32_t b = blk_of(row_to_stored(ix.primary, row), pos);
+                Blk x;
+                load_blk(ix.blocks, b, x);
+                const int c = blk_sym(x, pos);
+                if (c != text_sym(ix, p - 1)) ++bad_sym;
+                row = L2_of(ix, c) + blk_count1(x, pos + 1, c);
+                --p;
+            }
+            ++steps;
+        } while ((row & (bwtint)(ix.sa_intv - 1)) != 0 && steps < 100000ull);
+        if ((row & (bwtint)(ix.sa_intv - 1)) != 0) ++bad_sa;       // an arc that never closes
+        else {
+            const bwtint t2 = row / (bwtint)ix.sa_intv;
+            const bwtint want = t2 == 0 ? ix.seq_len : sa_sample(ix, t2);
+            if (want != p) ++bad_sa;
+        }
+        rows += steps;
+        if (steps > longest) longest = steps;
+    }
+    rows = wave_sum(rows); bad_sym = wave_sum(bad_sym); bad_sa = wave_sum(bad_sa);
+    for (int o = 32; o > 0; o >>= 1) { const unsigned long long v = __shfl_xor(longest, o, 64); longest = v > longest ? v : longest; }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(out + 0, rows); atomicAdd(out + 1, bad_sym); atomicAdd(out + 2, bad_sa); atomicMax(out + 3, longest); }
+}
+void launch_index_check(const IndexView &ix, unsigned long long *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_index_check, dim3(256 * 16), dim3(256), 0, s, ix, out);
 }
 
 // ---- banded global alignment of gapped hits ---------------------------------

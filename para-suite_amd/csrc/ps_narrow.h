@@ -188,6 +188,13 @@ PS_HD int nt_seq_at(const BtMem &m, const NLane &L, int j, int len, int max_len)
     return ((nw >> (p & 31)) & 1u) ? 4 : 3 - (int)b;
 }
 
+// The head of an EMPTY bucket is NIL: set when a read is taken (here) and when a pop empties a bucket (nt_pop), so that a push
+// links `next = head` without asking the bitmap whether the bucket holds anything (nine tests and selects less per expansion)
+PS_HD void nt_heads_init(BtMem &m, int n_buckets)
+{
+    uint32_t *hw = reinterpret_cast<uint32_t *>(m.heads16);
+    for (int p = 0; p < (n_buckets + 1) >> 1; ++p) hw[p] = 0xFFFFFFFFu;
+}
 PS_HD void nt_finish_read(const BtArgs &a, NLane &L)
 {
     a.n_aln[L.r] = nl_n_aln(L.ctl);
@@ -293,6 +300,7 @@ PS_COLD bool nt_fetch(const BtArgs &a, NLane &L, BtMem &m, int q)
     L.kr = 0; L.lr = (uint32_t)a.ix.seq_len; L.wa = (uint32_t)len; L.wb = NW_ROOT_C << 6;     // the root: i = len, state M, score 0
     L.ctl |= NL_HAVE_CUR;
     L.nsb = 0; L.bm0 = 0; L.fh = 0xffffu; L.n_phantom = 0;
+    nt_heads_init(m, md.n_buckets);
     return true;
 }
 
@@ -314,7 +322,7 @@ PS_HD void nt_push(NLane &L, BtMem &m, uint32_t kr, uint32_t lr, uint32_t wa, ui
     const int score = nw_score(wb);
     const unsigned long long bit = 1ull << score;
     const uint32_t idx = nt_slot(L);
-    const uint32_t next = (L.bm0 & bit) ? (uint32_t)m.heads16[score] : PS_NIL16;
+    const uint32_t next = (uint32_t)m.heads16[score];        // NIL while the bucket is empty (nt_heads_init, nt_pop)
     Entry16 e; e.k = kr; e.l = lr; e.a = wa; e.b = wb | (next << 16);
     store16(reinterpret_cast<Entry16 *>(m.pool) + idx, e);
     m.heads16[score] = (uint16_t)idx;
@@ -337,7 +345,8 @@ PS_HD void nt_pop(NLane &L, BtMem &m)
     load16(reinterpret_cast<const Entry16 *>(m.pool) + hd, e);
     const uint32_t next = e.b >> 16;
     L.fh = hd;
-    if (next == PS_NIL16) { if (NB32) L.bm0 = (uint32_t)L.bm0 & ~(1u << b); else L.bm0 &= ~(1ull << b); } else m.heads16[b] = (uint16_t)next;
+    m.heads16[b] = (uint16_t)next;                           // NIL when this was the bucket's last entry
+    if (next == PS_NIL16) { if (NB32) L.bm0 = (uint32_t)L.bm0 & ~(1u << b); else L.bm0 &= ~(1ull << b); }
     L.kr = e.k; L.lr = e.l; L.wa = e.a; L.wb = e.b & 0xffffu;
     L.nsb -= 1u;
 }
@@ -467,34 +476,36 @@ PS_HD void nt_tail(const BtHot &h, NLane &L, LaneStats &st, BtMem &m, const NtSt
     const uint32_t wa_keep = L.wa & NW_KEEP, pos2 = (uint32_t)i | ((uint32_t)i << 8);       // children are differences: last_diff_pos = i
     const uint32_t wb0 = L.wb & 0x1ffu;                                         // n_ins, n_del, c (the score is set per child)
     const uint32_t pkr = L.kr, plr = L.lr;
-    // A child is popped only to be dropped when the budget left after it cannot pay for the differences its
-    // remaining bases need at least (the check every pop starts with).  The budget only ever shrinks, so such a
-    // child is dropped whenever it is popped: it is not stored at all, only counted (n_phantom) for the
-    // stack-size stop rule.  In profile mode this is about half of all pops.
-    uint32_t phantom = 0;
+    // A child that costs c units is a candidate iff c <= rem (it fits the budget).  It is popped only to be dropped when the budget
+    // left after it cannot pay for the differences its remaining bases need at least (the check every pop starts with) --
+    // floor((rem - c) / c_min) < bound, i.e. c > rem - bound * c_min.  The budget only ever shrinks, so such a child is dropped
+    // whenever it is popped: it is not stored at all, only counted (n_phantom) for the stack-size stop rule.  In profile mode this
+    // is about half of all pops.  One threshold per bound, two compares per child.
+    const int thr_same = rem - (int)ps_mul24((uint32_t)bnd_same, h.c_min), thr_del = rem - (int)ps_mul24((uint32_t)bnd_del, h.c_min);
+    uint32_t phantom = 0, gmask = 0;
     // ---- which children are stored, and their scores (push order: insertion, deletion of A C G T, mismatches) ----
-    bool g[9]; int sc[9];
+    int sc[9];
     uint32_t wa_i, wa_d;
     {   // insertion child: opens from M, extends from I; keeps the parent's interval
         const bool open = from_m && e_go < h.max_gapo(), ext = from_i && e_ge < h.max_gape();
-        const int un = e_un + (open ? h.u_gapo_ins() : h.u_gape());
+        const int c = open ? h.u_gapo_ins() : h.u_gape();
         sc[0] = e_sc + (open ? h.s_gapo_ins() : h.s_gape());
-        const bool cand = gap_ok && (open || ext) && un <= max_units;
-        g[0] = cand && (int)(ps_mul24((uint32_t)(max_units - un), inv) >> 16) >= bnd_same;
-        phantom += (cand && !g[0]) ? 1u : 0u;
+        const bool cand = gap_ok && (open || ext) && c <= rem, go = cand && c <= thr_same;
+        gmask |= go ? 1u : 0u;
+        phantom += (cand && !go) ? 1u : 0u;
         wa_i = wa_keep + pos2 + ((uint32_t)ST_I << 24) + (open ? 1u << 26 : 1u << 29);
     }
     {   // deletion children: open from M, extend from D; the four share score, counts and position (they stay at i+1)
         const uint32_t occ = tm ? plr : plr - pkr + 1u;    // never the root here (from_d)
         const bool open = from_m && e_go < h.max_gapo();
         const bool ext = from_d && e_ge < h.max_gape() && ((e_ge + e_go) * h.u_tight() < max_units || occ < (uint32_t)h.max_del_occ());
-        const int un = e_un + (open ? h.u_gapo_del() : h.u_gape());
+        const int c = open ? h.u_gapo_del() : h.u_gape();
         const int scd = e_sc + (open ? h.s_gapo_del() : h.s_gape());
-        const bool cand = gap_ok && (open || ext) && un <= max_units;
-        const bool go = cand && (int)(ps_mul24((uint32_t)(max_units - un), inv) >> 16) >= bnd_del;
-        if (cand && !go) phantom += (ck[0] < cl[0]) + (ck[1] < cl[1]) + (ck[2] < cl[2]) + (ck[3] < cl[3]);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { g[1 + c] = go && ck[c] < cl[c]; sc[1 + c] = scd; }
+        const bool cand = gap_ok && (open || ext) && c <= rem, go = cand && c <= thr_del;
+        const uint32_t ne = (ck[0] < cl[0] ? 2u : 0u) | (ck[1] < cl[1] ? 4u : 0u) | (ck[2] < cl[2] ? 8u : 0u) | (ck[3] < cl[3] ? 16u : 0u);
+        gmask |= go ? ne : 0u;
+        if (cand && !go) phantom += ps_popc(ne);
+        sc[1] = sc[2] = sc[3] = sc[4] = scd;
         wa_d = wa_keep + ((uint32_t)(i + 1) | ((uint32_t)(i + 1) << 8)) + ((uint32_t)ST_D << 24) + (open ? 1u << 26 : 1u << 29);
     }
     const bool do_mm = allow_diff && allow_M;
@@ -504,36 +515,34 @@ PS_HD void nt_tail(const BtHot &h, NLane &L, LaneStats &st, BtMem &m, const NtSt
     for (int j = 1; j <= 4; ++j) {
         const int c = (s + j) & 3;
         xk[j - 1] = sel4(ck, c); xl[j - 1] = sel4(cl, c);
-        const bool ok = xk[j - 1] < xl[j - 1];
-        g[4 + j] = false; sc[4 + j] = 0;
+        sc[4 + j] = 0;
         if (j < 4 || s > 3) {          // mismatch children (the fourth only for an N in the read)
-            const int un = e_un + (int)((u_word >> (8 * c)) & 0xffu);
+            const int cu = (int)((u_word >> (8 * c)) & 0xffu);
             sc[4 + j] = e_sc + (int)((s_word >> (8 * c)) & 0xffu);
-            const bool cand = do_mm && ok && un <= max_units;
-            g[4 + j] = cand && (int)(ps_mul24((uint32_t)(max_units - un), inv) >> 16) >= bnd_same;
-            phantom += (cand && !g[4 + j]) ? 1u : 0u;
+            const bool cand = do_mm && xk[j - 1] < xl[j - 1] && cu <= rem, go = cand && cu <= thr_same;
+            gmask |= go ? 1u << (4 + j) : 0u;
+            phantom += (cand && !go) ? 1u : 0u;
         }
     }
-    // ---- pass 1: slots and bucket heads.  Local memory executes a wave's accesses in order, so every head read below
-    // sees the head writes before it; nothing is waited for until all of them are under way. ----
-    uint32_t idx[9], raw[9], valid = 0;
+    // ---- slots: the one popped last first, then fresh ones, all at once (rank of a child among the stored ones) ----
+    const uint32_t n_push = ps_popc(gmask), fr = L.fh;
+    const bool reuse = fr != 0xffffu && n_push != 0u;
+    const uint32_t slot0 = (L.nsb >> 16) - (reuse ? 1u : 0u);
+    L.nsb += n_push + ((n_push - (reuse ? 1u : 0u)) << 16);
+    L.fh = n_push ? 0xffffu : fr;
+    if (STATS) st.pushes += n_push;
+    // ---- pass 1: bucket heads.  Local memory executes a wave's accesses in order, so every head read below sees the head
+    // writes before it; nothing is waited for until all of them are under way.  (An empty bucket's head is NIL: nt_heads_init.) ----
+    uint32_t idx[9], raw[9];
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
         idx[j] = 0; raw[j] = 0;
-        if (g[j]) {
-            idx[j] = nt_slot(L);
+        if ((gmask >> j) & 1u) {
+            const uint32_t rank = ps_popc(gmask & ((1u << j) - 1u));
+            idx[j] = (reuse && rank == 0u) ? fr : slot0 + rank;
             raw[j] = m.heads16[sc[j]];
             m.heads16[sc[j]] = (uint16_t)idx[j];
-            if (NB32) {
-                const uint32_t bit = 1u << sc[j], lo = (uint32_t)L.bm0;
-                valid |= (lo & bit) ? 1u << j : 0u;
-                L.bm0 = lo | bit;
-            } else {
-                const unsigned long long bit = 1ull << sc[j];
-                valid |= (L.bm0 & bit) ? 1u << j : 0u;
-                L.bm0 |= bit;
-            }
-            if (STATS) ++st.pushes;
+            if (NB32) L.bm0 = (uint32_t)L.bm0 | (1u << sc[j]); else L.bm0 |= 1ull << sc[j];
         }
     }
 #ifdef __HIP_DEVICE_COMPILE__
@@ -543,20 +552,20 @@ PS_HD void nt_tail(const BtHot &h, NLane &L, LaneStats &st, BtMem &m, const NtSt
 #endif
     // ---- pass 2: the entries ----
     Entry16 *const pool = reinterpret_cast<Entry16 *>(m.pool);
-#define NT_NEXT(j) ((((valid >> (j)) & 1u) ? raw[j] : PS_NIL16) << 16)
-    if (g[0]) { Entry16 e; e.k = pkr; e.l = plr; e.a = wa_i; e.b = (wb0 + 1u) | ((uint32_t)sc[0] << 9) | NT_NEXT(0); store16(pool + idx[0], e); }
+#define NT_NEXT(j) (raw[j] << 16)
+    if (gmask & 1u) { Entry16 e; e.k = pkr; e.l = plr; e.a = wa_i; e.b = (wb0 + 1u) | ((uint32_t)sc[0] << 9) | NT_NEXT(0); store16(pool + idx[0], e); }
     {
         const uint32_t wb_d = ((wb0 & 0x3fu) + (1u << 3)) | ((uint32_t)sc[1] << 9);
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-            if (g[1 + c]) { Entry16 e; e.k = ctm ? (pkr << 2) | (uint32_t)c : ck[c] + 1u; e.l = ctm ? cl[c] - ck[c] : cl[c]; e.a = wa_d; e.b = wb_d | ((uint32_t)c << 6) | NT_NEXT(1 + c); store16(pool + idx[1 + c], e); }
+            if ((gmask >> (1 + c)) & 1u) { Entry16 e; e.k = ctm ? (pkr << 2) | (uint32_t)c : ck[c] + 1u; e.l = ctm ? cl[c] - ck[c] : cl[c]; e.a = wa_d; e.b = wb_d | ((uint32_t)c << 6) | NT_NEXT(1 + c); store16(pool + idx[1 + c], e); }
     }
     {
         const uint32_t wa_x = wa_keep + pos2 + (1u << 16), wb_x = wb0 & 0x3fu;
 #pragma unroll
         for (int j = 1; j <= 4; ++j) {
             const uint32_t c = (uint32_t)((s + j) & 3);
-            if (g[4 + j]) { Entry16 e; e.k = ctm ? (pkr << 2) | c : xk[j - 1] + 1u; e.l = ctm ? xl[j - 1] - xk[j - 1] : xl[j - 1]; e.a = wa_x; e.b = wb_x | (c << 6) | ((uint32_t)sc[4 + j] << 9) | NT_NEXT(4 + j); store16(pool + idx[4 + j], e); }
+            if ((gmask >> (4 + j)) & 1u) { Entry16 e; e.k = ctm ? (pkr << 2) | c : xk[j - 1] + 1u; e.l = ctm ? xl[j - 1] - xk[j - 1] : xl[j - 1]; e.a = wa_x; e.b = wb_x | (c << 6) | ((uint32_t)sc[4 + j] << 9) | NT_NEXT(4 + j); store16(pool + idx[4 + j], e); }
         }
     }
 #undef NT_NEXT

@@ -228,7 +228,7 @@ int hs_unit_rows33(void)
         a0.ix.L2[1] = 0x90000000ull; a0.ix.L2[2] = 0x120000000ull; a0.ix.L2[3] = 0x1B0000000ull; a0.ix.seq_len = 0x1F0000123ull;
         BtHot a; if (!bt_hot_make(a0, a)) return 7;
         {
-            NLane N; nl_init(N);
+            NLane N; nl_init(N); nt_heads_init(m, 64);
             const uint32_t wa = 17u | (17u << 8) | (3u << 16) | (((uint32_t)ST_D | (2u << 2) | (5u << 5)) << 24), wb = 7u | (6u << 3) | (3u << 6) | (9u << 9);
             nt_push(N, m, (uint32_t)k, (uint32_t)l, wa, wb);
             N.kr = N.lr = N.wa = N.wb = 0;

@@ -68,6 +68,15 @@ def big(tmp_path_factory):
     return dict(torch=torch, dev=dev, contigs=contigs, fa=fa, ctx=ctx, info=info, text=IP.Text(fwd), bwt_all=bwt_all, oix=oix, tmp=tmp)
 
 
+def test_every_row_against_the_text(big):
+    """all 4.4e9 rows, not a sample: the LF cycle of the index spells the packed text (compared with the FASTA in the fixture) and
+    every SA sample holds the position counted along it (ps_ctx_index_check; tests/test_gpu_index_check.py has the negative controls)"""
+    r = big["ctx"].index_check()
+    assert r["rows"] == big["info"].seq_len + 1, r
+    assert r["bad_symbols"] == 0 and r["bad_samples"] == 0, r
+    print("index check at 2.2 Gbp: %d rows visited, longest arc between two SA samples %d rows" % (r["rows"], r["longest_arc"]))
+
+
 def test_index_from_the_text(big):
     """the index checked WITHOUT trusting it: properties computed from the text (tests/index_props.py; the same check fails on a
     suffix array with unsorted ties, swapped neighbours or a wrong position bit: tests/test_index_props_cpu.py)"""
