@@ -73,7 +73,7 @@ def gen_genome(torch, dev, total_bp, n_contigs, seed):
     return out
 
 
-def add_repeats(torch, dev, contigs, seed, share=0.45, info=None):
+def add_repeats(torch, dev, contigs, seed, share=0.45, info=None, satellite_reps=400):
     """Repeat structure of a mammalian genome on top of gen_genome's text (bench.py --genome-profile repeats): interspersed
     families -- 300-bp units (SINE-like: one family with a copy per ~2.6 kb, minor ones with 10^3-10^5 copies at full scale)
     and 6-kb units (LINE-like, most copies truncated at their 5' end) -- every copy 2-20 % diverged from its family's consensus
@@ -131,10 +131,10 @@ def add_repeats(torch, dev, contigs, seed, share=0.45, info=None):
             dst = (torch.rand(m, generator=g, device=dev, dtype=torch.float64) * (n - 361)).long()
             codes[(dst[:, None] + ar)[ok]] = seq[ok]
         # satellite arrays: ~0.3 % of the contig in arrays of 171-bp units
-        n_arr = max(1, int(n * 0.003) // (171 * 400))
+        n_arr = max(1, int(n * 0.003) // (171 * satellite_reps))
         for _ in range(n_arr):
             unit = torch.randint(0, 4, (171,), generator=g, device=dev, dtype=torch.uint8)
-            reps = 400
+            reps = satellite_reps
             arr = unit.repeat(reps)
             mut = torch.rand(arr.numel(), generator=g, device=dev) < 0.015
             arr = torch.where(mut, (arr + torch.randint(1, 4, (arr.numel(),), generator=g, device=dev, dtype=torch.uint8)) & 3, arr)
@@ -584,7 +584,7 @@ def main():
         drain = None
         if world == 1 and args.drain and S == 1:
             rows = []
-            for div in (8, 4, 2, 1):
+            for div in (64, 8, 4, 2, 1):
                 nb = max(1, n_mine // div)
                 sb = batches[0] if div == 1 else ctx.batch_from_codes(codes[:nb])
                 w_, k_ = [], []
@@ -599,8 +599,12 @@ def main():
                     sb.free()
             full = rows[-1]["ms_step"]
             drain = {"single_launch_steps": rows,
-                     "implied_speedup": {str(g): full / r["ms_step"] for g, r in zip((8, 4, 2), rows[:3])},
-                     "note": "one step (search + samse stages) over the first 1/8, 1/4, 1/2 and all of the batch, each alone on the GPU, best of two; "
+                     "implied_speedup": {str(g): full / r["ms_step"] for g, r in zip((8, 4, 2), rows[1:4])},
+                     "floor": "the first row holds fewer reads than the launch has lanes (262,144): every read has a lane to itself from the start, and the launch "
+                              "still takes ms_backtrack -- the time of its LONGEST search (up to 126,000 dependent iterations of ~2.5 us for a wave that has "
+                              "the SIMD to itself; the best-first order makes a read's iterations sequential).  No hand-out order or batch size gets a "
+                              "launch below that; what hides it is the next launch (--pipeline 2), which is how the timed steps run",
+                     "note": "one step (search + samse stages) over the first 1/64, 1/8, 1/4, 1/2 and all of the batch, each alone on the GPU, best of two; "
                              "implied_speedup[G] = T(all) / T(1/G): what G GPUs can reach on this job (--scaling strong) before any multi-GPU cost"}
         n_bt = max(1, acc["n_backtrack_launches"])
         ms_bt_sum_step = acc["ms_backtrack"] / K          # summed over the launches of a step (two lanes overlap in time)

@@ -46,6 +46,7 @@ typedef struct ps_ctx ps_ctx;
 typedef struct ps_batch ps_batch;
 
 ps_ctx *ps_ctx_open(const char *ref_fa, int device);                 /* load <ref_fa>.bwt ... into HBM  */
+ps_ctx *ps_ctx_clone(ps_ctx *src, int device);                  /* a context on `device` with a device-to-device copy of src's index (what ps_map gives every device after the first) */
 ps_ctx *ps_ctx_build(const char *ref_fa, int device, int save_files);/* build the index (GPU), keep it resident */
 void    ps_ctx_close(ps_ctx *);
 int     ps_ctx_set_stock(ps_ctx *, const char *n_arg);               /* bwa aln -n */
@@ -65,6 +66,7 @@ typedef struct {                       /* index geometry + build facts */
     uint64_t seq_len, l_pac, primary, L2[5], n_blocks, n_sa, device_bytes;
     int32_t n_contigs, n_holes, sa_rounds, sa_intv;
     double build_ms;
+    int32_t  jump_levels, pad_;        /* levels of the jump table derived from the index on the device (0: none) */
 } ps_index_info;
 int     ps_ctx_info(ps_ctx *, ps_index_info *out);
 /* index blobs (0 Occ blocks, 1 sampled SA, 2 pac) for the one-off RCCL broadcast over xGMI */
@@ -122,6 +124,12 @@ int     ps_parse_check(const char *reads_path, int threads, uint64_t chunk_bytes
 typedef struct { uint64_t n_in, n_out, bam_bytes; } ps_bam_stats;
 int     ps_sam_to_bam(const char *sam, const char *bam, int min_mapq, int sort_by_coordinate, int write_index, int threads,
                       ps_bam_stats *stats /* may be NULL */);
+/* ps_map and the steps above in ONE call, without the SAM text in between (PARAsuiteMapping.java:63-152 end to end: `bwa parasuite|aln`,
+ * `bwa samse`, `samtools view -bS`, `view -q`, and Mapping.java:85-108's sort + index): alignment records -> BAM records -> BGZF, piece by
+ * piece while later pieces of the input are searched.  out_bam holds the records with MAPQ >= min_mapq in input order, or sorted by
+ * coordinate (+ <out_bam>.bai with write_index).  Record for record what ps_sam_to_bam(ps_map(...)) writes. */
+int     ps_map_to_bam(int threads, const char *mm, const char *error_profile, const char *indel_profile, const char *ref_fa, const char *fastq,
+                      const char *out_bam, int min_mapq, int sort_by_coordinate, int write_index, ps_bam_stats *stats /* may be NULL */);
 /* the same steps one by one on BAM input, as the unmodified Java issues them (an argv-compatible `samtools` for exactly
  * these four command shapes is built as para-suite_amd/bin/samtools):
  *   samtools view -q <mapq> -b in.bam -o out.bam   (PARAsuiteMapping.java:121-133)

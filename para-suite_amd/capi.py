@@ -16,7 +16,7 @@ class IndexInfo(C.Structure):
     _fields_ = [("seq_len", C.c_uint64), ("l_pac", C.c_uint64), ("primary", C.c_uint64), ("L2", C.c_uint64 * 5),
                 ("n_blocks", C.c_uint64), ("n_sa", C.c_uint64), ("device_bytes", C.c_uint64),
                 ("n_contigs", C.c_int32), ("n_holes", C.c_int32), ("sa_rounds", C.c_int32), ("sa_intv", C.c_int32),
-                ("build_ms", C.c_double)]
+                ("build_ms", C.c_double), ("jump_levels", C.c_int32), ("pad_", C.c_int32)]
 
 
 class Timing(C.Structure):
@@ -41,7 +41,7 @@ HIT_DTYPE = np.dtype([("pos", "<i8"), ("sa", "<u8"), ("type", "<i4"), ("strand",
 
 EXPORTS = ["ps_version", "ps_last_error", "ps_index", "ps_map", "ps_ctx_open", "ps_ctx_build", "ps_ctx_close",
            "ps_ctx_set_stock", "ps_ctx_set_profile", "ps_ctx_set_profile_matrix", "ps_ctx_set_tiers", "ps_ctx_set_stats", "ps_ctx_set_lanes", "ps_ctx_info",
-           "ps_ctx_blob", "ps_ctx_meta", "ps_ctx_from_blobs", "ps_ctx_fetch", "ps_ctx_export_blob", "ps_ctx_sa_lookup", "ps_ctx_index_check", "ps_sam_to_bam", "ps_bam_view", "ps_bam_sort", "ps_bam_index", "ps_batch_from_fastq",
+           "ps_ctx_blob", "ps_ctx_meta", "ps_ctx_from_blobs", "ps_ctx_clone", "ps_ctx_fetch", "ps_ctx_export_blob", "ps_ctx_sa_lookup", "ps_ctx_index_check", "ps_sam_to_bam", "ps_map_to_bam", "ps_bam_view", "ps_bam_sort", "ps_bam_index", "ps_batch_from_fastq",
            "ps_batch_from_codes", "ps_batch_free", "ps_batch_n", "ps_batch_search", "ps_batch_select_hard",
            "ps_batch_select_easy", "ps_batch_locate", "ps_batch_run", "ps_batch_write_sam", "ps_batch_n_aln",
            "ps_batch_alns", "ps_batch_hits", "ps_batch_timing", "ps_batch_kstats", "ps_ctx_read_iters", "ps_parse_check", "ps_error_profile", "ps_map_profiled", "ps_release_host_cache"]
@@ -139,6 +139,12 @@ class Ctx:
         c = cls(lib().ps_ctx_from_blobs(meta, len(meta), device, arr))
         c._keep = keep
         return c
+
+    def clone(self, device=0):
+        """a second context holding a device-to-device copy of this one's index (ps_map's route to every device after the first)"""
+        lib().ps_ctx_clone.restype = C.c_void_p
+        lib().ps_ctx_clone.argtypes = [C.c_void_p, C.c_int]
+        return Ctx(lib().ps_ctx_clone(self.h, int(device)))
 
     def close(self):
         if self.h:
@@ -370,6 +376,17 @@ def ps_sam_to_bam(sam, bam, min_mapq=0, sort_by_coordinate=False, write_index=Fa
     st = BamStats()
     _chk(L.ps_sam_to_bam(sam.encode(), bam.encode(), int(min_mapq), int(bool(sort_by_coordinate)), int(bool(write_index)),
                          int(threads), C.byref(st)))
+    return dict(n_in=st.n_in, n_out=st.n_out, bam_bytes=st.bam_bytes)
+
+
+def ps_map_to_bam(threads, mm, error_profile, indel_profile, ref_fa, fastq, out_bam, min_mapq=0, sort_by_coordinate=False, write_index=False):
+    """ps_map with the records going straight into a (MAPQ-filtered, optionally sorted + indexed) BAM: no SAM text in between"""
+    L = lib()
+    L.ps_map_to_bam.argtypes = [C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(BamStats)]
+    st = BamStats()
+    _chk(L.ps_map_to_bam(int(threads), str(mm).encode(), error_profile.encode() if error_profile else None,
+                         indel_profile.encode() if indel_profile else None, ref_fa.encode(), fastq.encode(), out_bam.encode(),
+                         int(min_mapq), int(bool(sort_by_coordinate)), int(bool(write_index)), C.byref(st)))
     return dict(n_in=st.n_in, n_out=st.n_out, bam_bytes=st.bam_bytes)
 
 

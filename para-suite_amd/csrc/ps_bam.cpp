@@ -40,7 +40,7 @@ inline int reg2bin(int64_t beg, int64_t end)
     return 0;
 }
 
-struct Rec { int32_t ref; int32_t pos; int32_t end; uint32_t flag; size_t off, len; int part; };   // encoded record: bytes [off, off+len) of its part
+typedef BamRec Rec;        // encoded record: bytes [off, off+len) of its part
 
 struct Field { const char *p; size_t n; };
 
@@ -422,7 +422,7 @@ static void write_bai(const std::string &bai_path, const Data &d, const Layout &
 }
 
 // ---- Data (records in d.recs order) -> BGZF file (+ .bai)
-static void write_bam(Data &d, const char *bam_path, bool write_index, int threads, BamStats *stats)
+static void write_bam(Data &d, const char *bam_path, bool write_index, int threads, BamStats *stats, int level = 6)
 {
     std::string head;
     head.append("BAM\1", 4); put32(head, (uint32_t)d.text.size()); head += d.text; put32(head, (uint32_t)d.refs.size());
@@ -446,8 +446,8 @@ static void write_bam(Data &d, const char *bam_path, bool write_index, int threa
         const int T = threads;
         par(T, T, [&](int t) {
             for (size_t k = (size_t)t; k < n_blocks; k += (size_t)T) {
-                if (k < head_blocks) { const size_t a0 = k * BLK; bgzf_block(head.data() + a0, std::min(BLK, head.size() - a0), 6, comp[k]); }
-                else { const size_t a0 = (k - head_blocks) * BLK; bgzf_block(stream.data() + a0, (size_t)std::min<uint64_t>(BLK, body_bytes - a0), 6, comp[k]); }
+                if (k < head_blocks) { const size_t a0 = k * BLK; bgzf_block(head.data() + a0, std::min(BLK, head.size() - a0), level, comp[k]); }
+                else { const size_t a0 = (k - head_blocks) * BLK; bgzf_block(stream.data() + a0, (size_t)std::min<uint64_t>(BLK, body_bytes - a0), level, comp[k]); }
             }
         });
     }
@@ -490,6 +490,71 @@ static void sort_records(Data &d, bool by_name)
 }  // namespace
 
 static int clamp_threads(int t) { return t < 1 ? 1 : (t > 64 ? 64 : t); }
+
+int bam_reg2bin(int64_t beg, int64_t end) { return reg2bin(beg, end); }
+
+// ---- records straight from memory (ps_map_to_bam)
+struct BamSink::Impl {
+    Data d; std::string path; bool sort = false, index = false; int threads = 1, level = 6;
+    FILE *f = nullptr; uint64_t bytes = 0, n_out = 0; bool failed = false;
+};
+BamSink::BamSink(const std::string &header_text, const std::vector<std::pair<std::string, uint32_t>> &refs, const char *bam_path,
+                 bool sort_by_coordinate, bool write_index, int threads, int level) : p(new Impl())
+{
+    if (write_index && !sort_by_coordinate) { delete p; p = nullptr; throw Err("a .bai index needs coordinate-sorted output"); }
+    p->d.text = header_text; p->d.refs = refs; p->path = bam_path; p->sort = sort_by_coordinate; p->index = write_index;
+    p->threads = clamp_threads(threads); p->level = level < 0 ? 0 : (level > 9 ? 9 : level);
+    if (p->sort) { header_sorted(p->d.text, "coordinate"); return; }
+    p->f = std::fopen(bam_path, "wb");
+    if (!p->f) { const std::string m = std::string("cannot write ") + bam_path; delete p; p = nullptr; throw Err(m); }
+    std::string head;
+    head.append("BAM\1", 4); put32(head, (uint32_t)p->d.text.size()); head += p->d.text; put32(head, (uint32_t)p->d.refs.size());
+    for (auto &r : p->d.refs) { put32(head, (uint32_t)r.first.size() + 1); head += r.first; head.push_back('\0'); put32(head, r.second); }
+    const size_t BLK = 0xff00;
+    for (size_t a0 = 0; a0 < head.size(); a0 += BLK) {
+        std::string blk; bgzf_block(head.data() + a0, std::min(BLK, head.size() - a0), p->level, blk);
+        if (std::fwrite(blk.data(), 1, blk.size(), p->f) != blk.size()) p->failed = true;
+        p->bytes += blk.size();
+    }
+}
+BamSink::~BamSink() { if (p) { if (p->f) std::fclose(p->f); delete p; } }
+void BamSink::add(std::vector<std::string> &records, std::vector<std::vector<BamRec>> &recs, uint64_t n_in)
+{
+    p->d.n_in += n_in;
+    if (p->sort) {
+        for (size_t k = 0; k < records.size(); ++k) {
+            const int part = (int)p->d.enc.size();
+            for (BamRec &r : recs[k]) r.part = part;
+            p->d.enc.push_back(std::move(records[k]));
+            p->d.recs.insert(p->d.recs.end(), recs[k].begin(), recs[k].end());
+        }
+        return;
+    }
+    // every buffer is cut into its own BGZF blocks (a record may span two blocks, a block never spans two buffers); all blocks of
+    // the call are compressed side by side
+    const size_t BLK = 0xff00;
+    std::vector<std::pair<size_t, size_t>> blk;              // (buffer, offset)
+    for (size_t k = 0; k < records.size(); ++k) { p->n_out += recs[k].size(); for (size_t a0 = 0; a0 < records[k].size(); a0 += BLK) blk.emplace_back(k, a0); }
+    std::vector<std::string> comp(blk.size());
+    const int T = p->threads;
+    par(T, T, [&](int t) { for (size_t j = (size_t)t; j < blk.size(); j += (size_t)T) { const std::string &src = records[blk[j].first]; bgzf_block(src.data() + blk[j].second, std::min(BLK, src.size() - blk[j].second), p->level, comp[j]); } });
+    for (size_t j = 0; j < comp.size(); ++j) { if (std::fwrite(comp[j].data(), 1, comp[j].size(), p->f) != comp[j].size()) p->failed = true; p->bytes += comp[j].size(); }
+    records.clear(); recs.clear();
+}
+void BamSink::finish(BamStats *stats)
+{
+    if (p->sort) {
+        sort_records(p->d, false);
+        write_bam(p->d, p->path.c_str(), p->index, p->threads, stats, p->level);
+        return;
+    }
+    static const unsigned char eof_block[28] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 66, 67, 2, 0, 27, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    bool ok = !p->failed && std::fwrite(eof_block, 1, 28, p->f) == 28;
+    ok = (std::fclose(p->f) == 0) && ok;
+    p->f = nullptr;
+    if (!ok) throw Err(std::string("short write on ") + p->path);
+    if (stats) { stats->n_in = p->d.n_in; stats->n_out = p->n_out; stats->bam_bytes = p->bytes + 28; }
+}
 
 void sam_to_bam(const char *sam_path, const char *bam_path, int min_mapq, bool sort_by_coordinate, bool write_index, int threads, BamStats *stats)
 {

@@ -6,6 +6,24 @@
 #include <vector>
 namespace ps {
 struct BamStats { uint64_t n_in = 0, n_out = 0, bam_bytes = 0; };
+// one encoded BAM record inside a buffer of records: reference id, 0-based position and end, flag, byte range [off, off + len)
+struct BamRec { int32_t ref; int32_t pos; int32_t end; uint32_t flag; size_t off, len; int part; };
+int bam_reg2bin(int64_t beg, int64_t end);                  // UCSC binning scheme (SAMv1 5.3)
+// BAM records that were never SAM text (ps_map_to_bam: straight from the alignment records in memory): parts arrive in input
+// order.  Unsorted output: a part is cut into BGZF blocks, compressed on `threads` threads and appended to the file at once, so the
+// compression of one piece of the input runs while the next is searched.  Coordinate-sorted output (+ .bai): the parts are kept and
+// sorted, compressed and written by finish().
+class BamSink {
+public:
+    BamSink(const std::string &header_text, const std::vector<std::pair<std::string, uint32_t>> &refs, const char *bam_path,
+            bool sort_by_coordinate, bool write_index, int threads, int level);
+    ~BamSink();
+    // buffers of records in input order (one per encoding thread); recs[k][i].off/len index into records[k]; both are consumed
+    void add(std::vector<std::string> &records, std::vector<std::vector<BamRec>> &recs, uint64_t n_in);
+    void finish(BamStats *stats);
+private:
+    struct Impl; Impl *p;
+};
 // all throw std::runtime_error; min_mapq: records with MAPQ below it are dropped (samtools view -q)
 void sam_to_bam(const char *sam_path, const char *bam_path, int min_mapq, bool sort_by_coordinate, bool write_index, int threads, BamStats *stats);
 void bam_view(const char *in_bam, const char *out_bam, int min_mapq, int threads, BamStats *stats);     // samtools view -q Q -b

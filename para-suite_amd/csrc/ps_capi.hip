@@ -60,6 +60,18 @@ static ps_ctx *new_ctx(int device)
     return x;
 }
 
+// a second context on `device` holding a COPY of src's index (blobs + jump table, device to device: the route ps_map takes for every
+// device after the first; src and the new context may be on the same device)
+ps_ctx *ps_ctx_clone(ps_ctx *src, int device)
+{
+    ps_ctx *x = nullptr;
+    PS_TRY
+        x = new_ctx(device);
+        index_clone(src->c.ix, src->c.device, x->c.ix, device, x->c.stream);
+        return x;
+    } catch (const std::exception &e) { delete x; fail(e.what()); return nullptr; } catch (...) { delete x; fail("unknown error"); return nullptr; }
+}
+
 ps_ctx *ps_ctx_open(const char *ref_fa, int device)
 {
     ps_ctx *x = nullptr;
@@ -178,7 +190,7 @@ int ps_ctx_info(ps_ctx *x, ps_index_info *o)
         for (int j = 0; j < 5; ++j) o->L2[j] = ix.view.L2[j];
         o->n_blocks = ix.view.n_blocks; o->n_sa = ix.view.n_sa; o->device_bytes = ix.device_bytes();
         o->n_contigs = (int)ix.ref.contigs.size(); o->n_holes = (int)ix.ref.holes.size(); o->sa_rounds = ix.sa_rounds; o->sa_intv = ix.view.sa_intv;
-        o->build_ms = ix.build_ms; return 0;
+        o->build_ms = ix.build_ms; o->jump_levels = ix.jump_levels; o->pad_ = 0; return 0;
     PS_CATCH_INT
 }
 int ps_ctx_blob(ps_ctx *x, int which, void **p, uint64_t *bytes)
@@ -357,9 +369,10 @@ int ps_batch_kstats(ps_batch *b, int which, ps_kstats *o)
 static const char *const PS_PG_LINE = "@PG\tID:parasuite-hip\tPN:parasuite-hip\tVN:0.1";
 namespace {
 struct ProfileSink { int min_mapq = 0, max_len = 0; std::string prefix; };    // ps_map_profiled: the first pass also counts its error profile
+struct BamOut { int min_mapq = 0; bool sort = false, index = false; int level = 1; BamStats *stats = nullptr; };   // ps_map_to_bam: out_sam names a BAM file
 }
 static int map_core(int threads, const char *mm, const char *error_profile, const char *indel_profile,
-                    const char *ref_fa, const char *fastq, const char *out_sam, const ProfileSink *sink)
+                    const char *ref_fa, const char *fastq, const char *out_sam, const ProfileSink *sink, const BamOut *bam = nullptr)
 {
     PS_TRY
         const bool verbose = std::getenv("PS_VERBOSE") != nullptr;
@@ -447,6 +460,7 @@ static int map_core(int threads, const char *mm, const char *error_profile, cons
         std::thread writer([&]() {
             try {
                 bool first = true;
+                std::unique_ptr<BamSink> bsink;                        // ps_map_to_bam: records go out as BAM, no SAM text at all
                 std::unique_ptr<ProfileAccum> accum;                   // on the first device, whose index is resident before any piece is finished
                 for (;;) {
                     std::unique_ptr<Batch> b;
@@ -459,7 +473,16 @@ static int map_core(int threads, const char *mm, const char *error_profile, cons
                         b = std::move(it->second); done.erase(it);
                     }
                     const auto t0 = std::chrono::steady_clock::now();
-                    batch_write_sam(*b, out_sam, first, PS_PG_LINE, nthr, !first);
+                    if (bam) {
+                        if (!bsink) {
+                            std::vector<std::pair<std::string, uint32_t>> refs;
+                            for (const Contig &ct : b->ctx->ix.ref.contigs) refs.emplace_back(ct.name, (uint32_t)ct.len);
+                            bsink.reset(new BamSink(sam_header(b->ctx->ix.ref, PS_PG_LINE), refs, out_sam, bam->sort, bam->index, nthr, bam->level));
+                        }
+                        std::vector<std::string> enc; std::vector<std::vector<BamRec>> recs;
+                        batch_bam_records(*b, bam->min_mapq, nthr, enc, recs);
+                        bsink->add(enc, recs, (uint64_t)b->rs.n);
+                    } else batch_write_sam(*b, out_sam, first, PS_PG_LINE, nthr, !first);
                     t_write += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
                     if (sink) {                                        // the same records, straight from memory, into the profile histograms
                         const auto tp = std::chrono::steady_clock::now();
@@ -479,11 +502,19 @@ static int map_core(int threads, const char *mm, const char *error_profile, cons
                 if (first) {                      // no reads at all: the header alone, as upstream's samse prints it before its read loop
                     { std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return failed || index_state[0] == 1; }); if (failed) return; }
                     const std::string h = sam_header(xs[0]->c.ix.ref, PS_PG_LINE);
-                    FILE *f = std::fopen(out_sam, "wb");
+                    if (bam) {
+                        std::vector<std::pair<std::string, uint32_t>> refs;
+                        for (const Contig &ct : xs[0]->c.ix.ref.contigs) refs.emplace_back(ct.name, (uint32_t)ct.len);
+                        bsink.reset(new BamSink(h, refs, out_sam, bam->sort, bam->index, nthr, bam->level));
+                    }
+                    FILE *f = bam ? nullptr : std::fopen(out_sam, "wb");
+                    if (bam) { /* the header-only BAM is written by finish() below */ } else {
                     if (!f) throw Error(std::string("cannot write ") + out_sam);
                     const bool ok = std::fwrite(h.data(), 1, h.size(), f) == h.size();
                     if (std::fclose(f) != 0 || !ok) throw Error(std::string("short write on ") + out_sam);
+                    }
                 }
+                if (bsink) { const auto t0 = std::chrono::steady_clock::now(); bsink->finish(bam->stats); bsink.reset(); t_write += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
                 if (sink) {
                     ProfileCounts pc;
                     if (accum) accum->finish(pc);
@@ -593,6 +624,23 @@ int ps_map_profiled(int threads, const char *mm, const char *error_profile, cons
     if (max_read_len < 1 || max_read_len > 4096) return fail("error profile: maximum read length out of range");
     ProfileSink sink; sink.min_mapq = min_mapq; sink.max_len = max_read_len; sink.prefix = profile_prefix;
     return map_core(threads, mm, error_profile, indel_profile, ref_fa, fastq, out_sam, &sink);
+}
+
+// ps_map with the records going straight into a BAM file: what PARAsuiteMapping.java:102-152 makes of <prefix>.sam with three
+// samtools calls (view -bS, view -q, and -- Mapping.java:85-108 -- sort + index), without the 2 GB of SAM text in between.  Records
+// with MAPQ < min_mapq are left out; sort_by_coordinate / write_index as in ps_sam_to_bam.  Unsorted output is compressed and written
+// piece by piece while later pieces are searched.  zlib level 1 by default (the BAM is 10 % larger than at samtools' level 6 and the call
+// 0.7 s shorter per 10 M reads: compression, not mapping, is what the host spends its time on); PS_BAM_LEVEL=6 for samtools' own.
+int ps_map_to_bam(int threads, const char *mm, const char *error_profile, const char *indel_profile,
+                  const char *ref_fa, const char *fastq, const char *out_bam, int min_mapq, int sort_by_coordinate, int write_index, ps_bam_stats *st)
+{
+    if (write_index && !sort_by_coordinate) return fail("a .bai index needs coordinate-sorted output");
+    BamStats s;
+    BamOut bo; bo.min_mapq = min_mapq; bo.sort = sort_by_coordinate != 0; bo.index = write_index != 0; bo.stats = &s;
+    if (const char *e = std::getenv("PS_BAM_LEVEL")) bo.level = std::atoi(e);
+    const int rc = map_core(threads, mm, error_profile, indel_profile, ref_fa, fastq, out_bam, nullptr, &bo);
+    if (rc == 0 && st) { st->n_in = s.n_in; st->n_out = s.n_out; st->bam_bytes = s.bam_bytes; }
+    return rc;
 }
 
 // page-locked host buffers the library keeps between calls (ps_pipeline.h, PinBuf): given back to the system

@@ -62,7 +62,8 @@ void launch_effort_model(const EffortModelArgs &a, hipStream_t s);
 // false: model outside the packed ranges.  stats: the narrow tiers' kernel with per-lane counters (KStats, read_iters); the timed kernel carries none
 // fills the jump table of an index (ps_core.h): `levels` levels, jump_words(levels) words at `table`
 void launch_jump_build(const IndexView &ix, uint32_t *table, int levels, hipStream_t s);
-bool launch_backtrack(const BtArgs &a, const BtArgs *d_args /* device copy, filled here */, int n_blocks, int lm_stride, hipStream_t s, bool stats);
+bool launch_backtrack(const BtArgs &a, const BtArgs *d_args /* device copy, filled here */, BtArgs *h_stage /* page-locked, one per stream: the source of that upload */,
+                      int n_blocks, int lm_stride, hipStream_t s, bool stats);
 void launch_index_check(const IndexView &ix, unsigned long long *out /* device: rows visited, symbol mismatches, sample mismatches, longest arc */, hipStream_t s);
 void launch_sa2pos(const IndexView &ix, const bwtint *rows, bwtint *out, int n, KStats *stats, hipStream_t s);
 void launch_refine(const RefineArgs &a, int n_blocks, hipStream_t s);

@@ -415,9 +415,12 @@ void launch_jump_build(const IndexView &ix, uint32_t *table, int levels, hipStre
         hipLaunchKernelGGL(k_jump_level, dim3(blocks), dim3(256), 0, s, h, table, ix.seq_len, d);
     }
 }
-bool launch_backtrack(const BtArgs &a_in, const BtArgs *d_args, int n_blocks, int lm_stride, hipStream_t s, bool stats)
+bool launch_backtrack(const BtArgs &a_in, const BtArgs *d_args, BtArgs *h_stage, int n_blocks, int lm_stride, hipStream_t s, bool stats)
 {
-    BtArgs a = a_in;
+    // the patched copy lives in the caller's page-locked staging buffer: it outlives the asynchronous upload whatever the runtime does
+    // with pageable sources (the caller synchronises the stream before it touches the buffer again)
+    BtArgs &a = *h_stage;
+    a = a_in;
     // the counting kernel counts the blocks of the plain algorithm (SURVEY.md 8d's figure), the wide tier keeps whole intervals
     // in its entries: both search without the jump table.  PS_JUMP=0: the timed kernel too (A/B measurements)
     const char *ej = std::getenv("PS_JUMP");

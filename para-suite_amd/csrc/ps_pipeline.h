@@ -5,6 +5,7 @@
 #include <memory>
 #include <mutex>
 #include "ps_host.h"
+#include "ps_bam.h"
 
 namespace ps {
 
@@ -152,6 +153,7 @@ void batch_select_hard(Batch &b, uint64_t draws_before, uint64_t *draws_after);
 void batch_select_easy(Batch &b, int threads);
 void reserve_search_workspace(Ctx *ctx, int work_index);        // the big device allocations of a lane of work, ahead of its first search
 void batch_locate(Batch &b);                                    // SA walk kernel, strand / MAPQ, banded DP of gapped hits
+void batch_bam_records(const Batch &b, int min_mapq, int threads, std::vector<std::string> &enc, std::vector<std::vector<BamRec>> &recs);   // the located batch as BAM records (MAPQ >= min_mapq): one buffer per thread, buffers in input order
 std::string sam_header(const RefSeq &ref, const char *pg_line);      // @SQ lines in FASTA order + the @PG line
 void batch_write_sam(Batch &b, const char *path, bool header, const char *pg_line, int threads, bool append = false);
 // the located hits with MAPQ >= min_mapq as records for the error-profile kernel (what the MAPQ-filtered BAM of the first pass holds:

@@ -647,7 +647,7 @@ static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases
     uint32_t *riters = nullptr;
     if (ctx->want_read_iters) { riters = wk->ws_get<uint32_t>("riters", (size_t)n * PS_RI_WORDS); PS_HIP(hipMemsetAsync(riters, 0, (size_t)n * PS_RI_WORDS * 4, s)); a.read_iters = riters; }
     { EvTimer t(s);
-      if (!launch_backtrack(a, wk->ws_get<BtArgs>("btargs", 1), blocks, lm, s, ctx->want_kstats || ctx->want_read_iters)) throw Error("cost model outside the ranges the search kernel packs (gap/score fields must fit a byte)");
+      if (!launch_backtrack(a, wk->ws_get<BtArgs>("btargs", 1), wk->pin_get<BtArgs>("btargs_h", 1), blocks, lm, s, ctx->want_kstats || ctx->want_read_iters)) throw Error("cost model outside the ranges the search kernel packs (gap/score fields must fit a byte)");
       PS_HIP(hipGetLastError());
       const double ms = t.stop(); b.tm.ms_backtrack += ms; ++b.tm.n_backtrack_launches;
       { double t0_ = 0, t1_ = 0; t.span(ctx->ref_event, t0_, t1_); if (b.tm.n_backtrack_launches == 1) b.tm.bt_begin_ms = t0_; b.tm.bt_end_ms = t1_; }
@@ -1421,6 +1421,21 @@ static void cal_md(const RefSeq &ref, int n_cigar, const uint32_t *cigar, int le
     put_int(md, u);
 }
 
+// the XA list of a read (alternative hits, `samse -n 3`): chr,(+|-)pos,CIGAR,NM;
+static void xa_text(const Batch &b, const Hit &h, int len, std::string &o)
+{
+    const RefSeq &ref = b.ctx->ix.ref;
+    for (int j = 0; j < h.n_multi; ++j) {
+        const Multi &m = b.multis[h.multi_begin + j];
+        int sid = 0;
+        ref.cnt_ambi(m.pos, (int)ref_span(m.n_cigar, m.cigar, len), &sid);
+        const Contig &mc = ref.contigs[sid];
+        o.append(mc.name); o.push_back(','); o.push_back(m.strand ? '-' : '+'); put_int(o, (long)(m.pos - mc.offset + 1)); o.push_back(',');
+        put_cigar(o, m.n_cigar, m.cigar, len);
+        o.push_back(','); put_int(o, m.gap + m.mm); o.push_back(';');
+    }
+}
+
 static void sam_line(const Batch &b, int64_t g, std::string &o)
 {
     const ReadSet &rs = b.rs; const RefSeq &ref = b.ctx->ix.ref; const Options &opt = b.ctx->opt;
@@ -1469,19 +1484,109 @@ static void sam_line(const Batch &b, int64_t g, std::string &o)
     if (h.c1 <= opt.max_top2) { o.append("\tX1:i:"); put_int(o, h.c2); }
     o.append("\tXM:i:"); put_int(o, h.n_mm); o.append("\tXO:i:"); put_int(o, h.n_gapo); o.append("\tXG:i:"); put_int(o, h.n_gapo + h.n_gape);
     o.append("\tMD:Z:"); o.append(md);
-    if (h.n_multi) {
-        o.append("\tXA:Z:");
-        for (int j = 0; j < h.n_multi; ++j) {
-            const Multi &m = b.multis[h.multi_begin + j];
-            int sid = 0;
-            ref.cnt_ambi(m.pos, (int)ref_span(m.n_cigar, m.cigar, len), &sid);
-            const Contig &mc = ref.contigs[sid];
-            o.append(mc.name); o.push_back(','); o.push_back(m.strand ? '-' : '+'); put_int(o, (long)(m.pos - mc.offset + 1)); o.push_back(',');
-            put_cigar(o, m.n_cigar, m.cigar, len);
-            o.push_back(','); put_int(o, m.gap + m.mm); o.push_back(';');
-        }
-    }
+    if (h.n_multi) { o.append("\tXA:Z:"); xa_text(b, h, len, o); }
     o.push_back('\n');
+}
+
+// ---- the same record as a BAM record (ps_map_to_bam: no SAM text in between).  Field for field what sam_line prints and
+// ps_bam.cpp's encode_line would make of it: tests/test_bam.py compares the two routes record by record.
+static inline void b_put32(std::string &o, uint32_t v) { char c[4] = {(char)(v & 0xff), (char)((v >> 8) & 0xff), (char)((v >> 16) & 0xff), (char)(v >> 24)}; o.append(c, 4); }
+static inline void b_put16(std::string &o, uint32_t v) { char c[2] = {(char)(v & 0xff), (char)((v >> 8) & 0xff)}; o.append(c, 2); }
+static inline void b_tag_int(std::string &o, const char *tag, long v)          // the smallest type that holds it, as htslib / encode_line
+{
+    o.push_back(tag[0]); o.push_back(tag[1]);
+    if (v < 0) {
+        if (v >= -128) { o.push_back('c'); o.push_back((char)(int8_t)v); }
+        else if (v >= -32768) { o.push_back('s'); b_put16(o, (uint32_t)(uint16_t)(int16_t)v); }
+        else { o.push_back('i'); b_put32(o, (uint32_t)(int32_t)v); }
+    } else if (v <= 255) { o.push_back('C'); o.push_back((char)(uint8_t)v); }
+    else if (v <= 65535) { o.push_back('S'); b_put16(o, (uint32_t)v); }
+    else { o.push_back('I'); b_put32(o, (uint32_t)v); }
+}
+// false: below the MAPQ filter (not stored)
+static bool bam_record(const Batch &b, int64_t g, int min_mapq, std::string &o, BamRec &r)
+{
+    const ReadSet &rs = b.rs; const RefSeq &ref = b.ctx->ix.ref; const Options &opt = b.ctx->opt;
+    Hit h; b.hit_of(g, h);
+    const int mapq = h.type == 0 ? 0 : h.mapq;
+    if (mapq < min_mapq) return false;
+    const int len = rs.len[g];
+    const uint8_t *seq = rs.seq.data() + rs.off[g];
+    const char *qual = rs.has_qual ? rs.qual.data() + rs.off[g] : nullptr;
+    size_t nl; const char *nm_ = rs.name(g, nl);
+    if (nl > 254) throw Error("read name longer than 254 characters");
+    int seqid = -1, flag = 4, nn = 0, n_cig = 0; int64_t pos = -1, end = 0;
+    uint32_t cig[PS_MAX_CIGAR + 1];
+    if (h.type != 0) {
+        const int span = (int)ref_span(h.n_cigar, h.cigar, len);
+        nn = ref.cnt_ambi(h.pos, span, &seqid);
+        const Contig &ct = ref.contigs[seqid];
+        flag = (h.pos + span - ct.offset > ct.len ? 4 : 0) | (h.strand ? 16 : 0);
+        pos = h.pos - ct.offset;
+        if (h.n_cigar) { for (int j = 0; j < h.n_cigar; ++j) { const uint32_t op = h.cigar[j] & 0xfu; cig[j] = (h.cigar[j] & ~0xfu) | (op == 3 ? 4u : op); } n_cig = h.n_cigar; }
+        else { cig[0] = (uint32_t)len << 4; n_cig = 1; }
+        end = pos + (span > 0 ? span : 1);
+    }
+    const size_t start = o.size();
+    b_put32(o, 0);
+    b_put32(o, (uint32_t)seqid); b_put32(o, (uint32_t)(int32_t)pos);
+    o.push_back((char)(uint8_t)(nl + 1)); o.push_back((char)(uint8_t)mapq);
+    b_put16(o, (uint32_t)bam_reg2bin(pos, end));
+    b_put16(o, (uint32_t)n_cig); b_put16(o, (uint32_t)flag);
+    b_put32(o, (uint32_t)len); b_put32(o, 0xFFFFFFFFu); b_put32(o, 0xFFFFFFFFu); b_put32(o, 0);
+    o.append(nm_, nl); o.push_back('\0');
+    for (int j = 0; j < n_cig; ++j) b_put32(o, cig[j]);
+    static const uint8_t NIB[5] = {1, 2, 4, 8, 15}, NIB_RC[5] = {8, 4, 2, 1, 15};
+    const bool rc = h.strand != 0;
+    {
+        const size_t at = o.size(), nb = (size_t)(len + 1) / 2;
+        o.resize(at + nb + (size_t)len);
+        uint8_t *d = reinterpret_cast<uint8_t *>(&o[at]);
+        for (int i = 0; i < len; i += 2) {
+            const uint8_t hi = rc ? NIB_RC[seq[len - 1 - i]] : NIB[seq[i]];
+            const uint8_t lo = i + 1 < len ? (rc ? NIB_RC[seq[len - 2 - i]] : NIB[seq[i + 1]]) : 0;
+            d[i >> 1] = (uint8_t)(hi << 4 | lo);
+        }
+        d += nb;
+        if (!qual) std::memset(d, 0xff, (size_t)len);
+        else if (!rc) for (int i = 0; i < len; ++i) d[i] = (uint8_t)(qual[i] - 33);
+        else for (int i = 0; i < len; ++i) d[i] = (uint8_t)(qual[len - 1 - i] - 33);
+    }
+    if (h.type != 0) {
+        uint8_t tmp_small[256]; std::vector<uint8_t> tmp_big;
+        uint8_t *tmp = tmp_small;
+        if (len > 256) { tmp_big.resize((size_t)len); tmp = tmp_big.data(); }
+        const uint8_t *oriented = seq;
+        if (rc) { for (int i = 0; i < len; ++i) { uint8_t c = seq[len - 1 - i]; tmp[i] = c > 3 ? c : (uint8_t)(3 - c); } oriented = tmp; }
+        static thread_local std::string md; md.clear(); int nm = 0;
+        cal_md(ref, h.n_cigar, h.cigar, len, h.pos, oriented, md, nm);
+        char XT = "NURM"[h.type];
+        if (nn > 10) XT = 'N';
+        o.append("XTA", 3); o.push_back(XT);
+        b_tag_int(o, "NM", nm);
+        if (nn) b_tag_int(o, "XN", nn);
+        b_tag_int(o, "X0", h.c1);
+        if (h.c1 <= opt.max_top2) b_tag_int(o, "X1", h.c2);
+        b_tag_int(o, "XM", h.n_mm); b_tag_int(o, "XO", h.n_gapo); b_tag_int(o, "XG", h.n_gapo + h.n_gape);
+        o.append("MDZ", 3); o.append(md); o.push_back('\0');
+        if (h.n_multi) { o.append("XAZ", 3); xa_text(b, h, len, o); o.push_back('\0'); }
+    }
+    const uint32_t bs = (uint32_t)(o.size() - start - 4);
+    o[start] = (char)(bs & 0xff); o[start + 1] = (char)((bs >> 8) & 0xff); o[start + 2] = (char)((bs >> 16) & 0xff); o[start + 3] = (char)(bs >> 24);
+    r.ref = seqid; r.pos = (int32_t)pos; r.end = (int32_t)end; r.flag = (uint32_t)flag; r.off = start; r.len = o.size() - start; r.part = 0;
+    return true;
+}
+// the records of a located batch that pass the MAPQ filter as BAM records: one buffer per host thread, the buffers in input order
+void batch_bam_records(const Batch &b, int min_mapq, int threads, std::vector<std::string> &enc, std::vector<std::vector<BamRec>> &recs)
+{
+    if (!b.located) throw Error("BAM records before locate");
+    const size_t N = (size_t)b.rs.n;
+    const int nt = par_threads(N, threads);
+    enc.assign((size_t)nt, std::string()); recs.assign((size_t)nt, std::vector<BamRec>());
+    par_for(N, threads, [&](size_t g0, size_t g1, int t) {
+        std::string &o = enc[t]; o.reserve((g1 - g0) * 176);
+        for (size_t g = g0; g < g1; ++g) { BamRec r; if (bam_record(b, (int64_t)g, min_mapq, o, r)) recs[t].push_back(r); }
+    });
 }
 
 void batch_profile_records(const Batch &b, int min_mapq, int threads, ProfRecords &out)

@@ -58,6 +58,17 @@ class Mapping:
                    sortByCoordinateAndIndex, sortByCoordinateAndIndex, threads)
         os.remove(outputPrefix + ".sam")
 
+    def _map_to_bam(self, what, threads, mm, ep, ip, reference, input, outputPrefix, mappingQualityFilter, sortByCoordinateAndIndex):
+        """the mapping call and samToFilteredBam fused (`ps_map_to_bam`): <prefix>.bam straight from the alignment records, the 2 GB of
+        <prefix>.sam per 10 M reads are never written; BGZF blocks are compressed while later pieces of the input are searched"""
+        if not os.path.exists(reference + ".bwt"):
+            self._call("bwa index " + reference, capi.ps_index, reference)
+        self.setTimeStart()
+        self._call(what + " | samtools view -bS | view -q %d%s" % (mappingQualityFilter, " | sort | index" if sortByCoordinateAndIndex else ""),
+                   capi.ps_map_to_bam, threads, mm, ep, ip, reference, input, outputPrefix + ".bam", mappingQualityFilter,
+                   sortByCoordinateAndIndex, sortByCoordinateAndIndex)
+        self.seconds = self.calculatePassedTime()
+
     @staticmethod
     def filter_sam_mapq(sam_in, sam_out, min_mapq):
         """what `samtools view -q Q` keeps (PARAsuiteMapping.java:121-133), on SAM text"""
@@ -77,6 +88,11 @@ class BWAMapping(Mapping):
         self._call("bwa aln -t %d -n %s %s %s | bwa samse" % (threads, additionalOptions, reference, input),
                    capi.ps_map, threads, additionalOptions, None, None, reference, input, outputPrefix + ".sam")
         self.seconds = self.calculatePassedTime()
+
+    def executeMappingToBam(self, threads, reference, input, outputPrefix, mappingQualityFilter, additionalOptions, sortByCoordinateAndIndex=False):
+        """executeMapping + samToFilteredBam in one library call (BWAMapping.java:51-128 end to end), no SAM file"""
+        self._map_to_bam("bwa aln -t %d -n %s %s %s | bwa samse" % (threads, additionalOptions, reference, input), threads, additionalOptions,
+                         None, None, reference, input, outputPrefix, mappingQualityFilter, sortByCoordinateAndIndex)
 
     def executeMappingWithProfile(self, threads, reference, input, outputPrefix, mappingQualityFilter, additionalOptions, maxReadLength):
         """the first pass of a --refine run and the ErrorProfiling step behind it (Main.java:288-334) as ONE call: the profile of
@@ -119,6 +135,14 @@ class PARAsuiteMapping(Mapping):
                    capi.ps_map, threads, additionalOptions, self.errorProfileFilename, self.indelProfileFilename,
                    reference, input, outputPrefix + ".sam")
         self.seconds = self.calculatePassedTime()
+
+    def executeMappingToBam(self, threads, reference, input, outputPrefix, mappingQualityFilter, additionalOptions, sortByCoordinateAndIndex=False):
+        """executeMapping + samToFilteredBam in one library call (PARAsuiteMapping.java:63-152 end to end), no SAM file"""
+        if not self.errorProfileFilename:
+            raise ExternalCallErrorException("bwa parasuite: no error profile set (-p)")
+        self._map_to_bam("bwa parasuite -t %d -X %s -p %s -g %s %s %s | bwa samse" %
+                         (threads, additionalOptions, self.errorProfileFilename, self.indelProfileFilename, reference, input), threads, additionalOptions,
+                         self.errorProfileFilename, self.indelProfileFilename, reference, input, outputPrefix, mappingQualityFilter, sortByCoordinateAndIndex)
 
 
 class ErrorProfiling:

@@ -29,7 +29,7 @@ def test_struct_layouts():
     import ctypes as C
     import capi
     assert capi.ALN_DTYPE.itemsize == 32 and capi.HIT_DTYPE.itemsize == 128
-    assert C.sizeof(capi.IndexInfo) == 8 * 11 + 4 * 4 + 8
+    assert C.sizeof(capi.IndexInfo) == 8 * 11 + 4 * 4 + 8 + 4 * 2
     assert C.sizeof(capi.KStats) == 64
 
 

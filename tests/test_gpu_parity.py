@@ -330,6 +330,27 @@ def test_ps_map_streams_in_pieces(mid, workdir, monkeypatch, capfd):
     assert not bad, (len(bad), g[bad[0]], o[bad[0]])
 
 
+def test_cloned_index_maps_identically(ctx_multi, multi, workdir):
+    """every device after the first gets its index from the first one, device to device (index_clone: blobs + the 2.9 GB jump
+    table at hg19 size).  One-GPU rehearsal: a second context on the SAME device with a cloned index must be the same index --
+    every row against the text (ps_ctx_index_check), the same meta / jump levels -- and map to the same SAM.  (Between two real
+    devices the copy is hipMemcpyPeerAsync over xGMI: that leg has no hardware run)"""
+    import orc
+    c2 = ctx_multi.clone(0)
+    i1, i2 = ctx_multi.info(), c2.info()
+    assert (i1.seq_len, i1.primary, list(i1.L2), i1.n_contigs, i1.jump_levels) == (i2.seq_len, i2.primary, list(i2.L2), i2.n_contigs, i2.jump_levels)
+    assert i2.jump_levels > 0
+    assert ctx_multi.meta() == c2.meta()
+    for k in range(3):
+        assert np.array_equal(ctx_multi.fetch(k), c2.fetch(k))
+    r = c2.index_check()
+    assert r["rows"] == i2.seq_len + 1 and r["bad_symbols"] == 0 and r["bad_samples"] == 0
+    fq = _fastq(multi["genome"], workdir, "clone", n_reads=3000, read_len=50, seed=17, indel_scale=30)
+    c2.set_stock("0.04")
+    _compare(c2, multi["orc_index"], orc.stock_opt("0.04"), fq, workdir, "clone")
+    c2.close()
+
+
 def test_ps_map_empty_fastq_writes_header(multi, workdir):
     """an input without reads: upstream's samse prints the @SQ header before its read loop (oracle/ps_oracle.c: orc_map_fastq
     does the same), so `samtools view -bS` (PARAsuiteMapping.java:103-110) still gets a valid SAM: ps_map must not leave 0 bytes"""

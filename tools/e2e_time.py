@@ -31,6 +31,12 @@ for w, rep in [(w, r) for w in workers for r in range(2)]:
     print('PS_WORKERS_PER_GPU=%d' % w, flush=True)
     t = time.time(); os.environ['PS_VERBOSE']='1'; capi.ps_map(16, '-1', '/tmp/e2e.errorprofile', '/tmp/e2e.indelprofile', fa, fq, '/tmp/e2e.sam'); dt = time.time() - t
     print('ps_map (index load + %d reads + SAM written) %.2fs = %.2f M reads/s, SAM %.0f MB' % (n, dt, n / dt / 1e6, os.path.getsize('/tmp/e2e.sam') / 1e6), flush=True)
+for lvl in (() if len(sys.argv) > 4 and sys.argv[4] == 'nobam' else ('6', '1')):            # the fused route: FASTQ -> filtered BAM, no SAM text
+    os.environ['PS_BAM_LEVEL'] = lvl
+    for kw in (dict(min_mapq=10), dict(min_mapq=10, sort_by_coordinate=True, write_index=True)):
+        t = time.time(); st = capi.ps_map_to_bam(16, '-1', '/tmp/e2e.errorprofile', '/tmp/e2e.indelprofile', fa, fq, '/tmp/e2e.fused.bam', **kw); dt = time.time() - t
+        print('ps_map_to_bam %s zlib level %s: %.2fs, %d of %d records kept, BAM %.0f MB' % (kw, lvl, dt, st['n_out'], st['n_in'], st['bam_bytes'] / 1e6), flush=True)
+os.environ.pop('PS_BAM_LEVEL', None)
 for args in (() if len(sys.argv) > 4 and sys.argv[4] == 'nobam' else (dict(min_mapq=10), dict(min_mapq=10, sort_by_coordinate=True, write_index=True))):
     t = time.time(); st = capi.ps_sam_to_bam('/tmp/e2e.sam', '/tmp/e2e.bam', threads=16, **args); dt = time.time() - t
     print('ps_sam_to_bam %s: %.2fs, %d of %d records kept, BAM %.0f MB' % (args, dt, st['n_out'], st['n_in'], st['bam_bytes'] / 1e6), flush=True)

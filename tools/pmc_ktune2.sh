@@ -1,6 +1,12 @@
 #!/bin/bash
 # Where the search kernel's waves wait: issue stalls, instruction fetch, vector-memory FIFOs, LDS conflicts, L1 TLB.
-# Counters only, one group per pass, each pass under its own timeout (a TA/TCP group hung the profiler once in round 1).
+# Counters only, one group per pass, each pass under its own timeout.
+# About the round-1 hang (tools/pmc2.sh, third group): that group was TA_BUSY / TA_ADDR_STALLED_BY_TC / TA_DATA_STALLED_BY_TC /
+# TA_FLAT_*_WAVEFRONTS plus TCP_PENDING_STALL_CYCLES; its pass never wrote a counter file (the two SQ groups before it did).  The one
+# counter it shares with this script, TCP_PENDING_STALL_CYCLES_sum, has since run to completion here together with the other TCP_*
+# counters below (round 2: all four passes "done" in the progress file, profiles/r02_wait_counters_1gbp_4m.txt), so the TA_* block
+# counters are what that pass hung on.  No TA_* counter is collected by any script that is still in use; pmc2.sh keeps its
+# warning and is not to be run.
 # usage: tools/pmc_ktune2.sh <tag> <ktune args...>
 tag=$1; shift
 export TMPDIR=/tmp
