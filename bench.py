@@ -644,7 +644,11 @@ def main():
             "value_scope": "search + samse stages on reads already packed in HBM -> per-read alignment records in pinned host memory "
                            "(FASTQ parsing, upload and SAM text are outside; see value_e2e)",
             "roofline": {"bound": "hbm", "kernel": "k_backtrack_n" if dominant_bt else "k_width",
-                         "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
+                         "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None, "traffic_source": None,
+                         "achieved_definition": "ALGORITHMIC bytes of the reference's algorithm (SURVEY.md 8d: 64 B per distinct Occ block of every search step, counted by "
+                                                "an untimed pass of the counting kernel WITHOUT the jump table) / the timed kernel's duration.  The timed kernel asks the "
+                                                "memory for less (requested_GBps: its own counters, 32-byte table slots for the shallow steps); measured HBM traffic is `traffic`",
+                         "algorithmic_GBps": ach,
                          "algorithmic_bytes_per_step": (alg_bt if dominant_bt else alg_w),
                          "algorithmic_bytes_per_launch": (alg_bt if dominant_bt else alg_w) / launches_per_step,
                          "launches_per_step": launches_per_step,
@@ -664,6 +668,8 @@ def main():
                                    "; counters from one extra untimed pass of the counting kernel over the same batch",
                          "requested_bytes_per_step": (64.0 * (2 * ks_timed.get("occ_pairs", 0) - ks_timed.get("occ_same_blk", 0)) +
                                                       32.0 * max(0, ks_bt["occ_pairs"] - ks_timed.get("occ_pairs", 0))) if dominant_bt else None,
+                         "requested_GBps": ((64.0 * (2 * ks_timed.get("occ_pairs", 0) - ks_timed.get("occ_same_blk", 0)) +
+                                             32.0 * max(0, ks_bt["occ_pairs"] - ks_timed.get("occ_pairs", 0))) / (ms_bt_union_step * 1e-3) / 1e9) if dominant_bt else None,
                          "requested_bytes_note": "what the timed kernel asks the memory for in search steps: 64 B per distinct Occ block of the steps it takes through "
                                                  "the Occ array (its own two counters) + 32 B per step answered by the jump table (DESIGN.md section 2); the algorithmic "
                                                  "bytes above are those of the reference's algorithm, counted without the table",

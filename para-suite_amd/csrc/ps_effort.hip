@@ -13,16 +13,18 @@
 //     w_pin rows), take the cheapest substitution that continues it; else start a new piece and charge an average mismatch.  A
 //     difference inside the first ~16 bases of a piece is not seen where it is (the interval still holds random matches) and
 //     several of them collapse into one restart, so one scan runs from either end of the read (the index holds both strands):
-//     a scan that never had to start over is exact; if both had to, the larger total counts.  Three substitutions within a few bases of each other are an indel or a wrong locus (the
-//     read is shifted against the text from there on and would pay a substitution per base): what they were charged goes back
-//     and one gap opening is charged with a new piece instead.  Measured on 10 M simulated PAR-CLIP reads: the final budget
-//     is hit exactly for 92 % of the reads, over-estimated for 8 %, under-estimated for 0.03 % (profiles/r03_order_probe.txt).
+//     a scan that never had to start over is exact; if both had to, the larger total counts.  Three substitutions within a few
+//     bases of each other are an indel, a wrong locus or three real differences: they stay charged and the scan goes on with a
+//     new piece (the read may be shifted against the text from there on and would pay a substitution per base).  Measured on
+//     10 M simulated PAR-CLIP reads: the final budget is hit exactly for 92 % of the reads, over-estimated for 7 %
+//     (profiles/r03_order_probe.txt).
 //  2. k_effort_model: within one budget the effort still varies 1:10 with the lower bounds D(i) the width stage computed (they
 //     prune the search: a read whose differences sit where the bounds cannot see them is searched almost exhaustively).  The
 //     number of nodes the search expands is estimated by running its own rules on EXPECTED counts: W[u] = expected live partial
 //     alignments with u units spent after d bases, children by the cost table, pruned by exactly the tests of ps_narrow.h
-//     (budget, D(i) bound, seed budget), random continuations weighted by min(1, rows / 4^d).  Against the true iteration
-//     counts: r = 0.99 on the log scale with the true budget, 0.8 inside the heaviest budget class (profiles/r03_order_probe.txt).
+//     (budget, D(i) bound, seed budget, where an indel may open), random continuations weighted by min(1, rows / 4^d).  Against
+//     the true iteration counts: r = 0.99 on the log scale with the true budget, 0.93 inside the heaviest budget class, and the
+//     200 heaviest of 400,000 reads all land in the first 0.2 % of the order (profiles/r03_order_probe.txt).
 //  3. run_search (ps_pipeline.hip) sorts the reads by the quantised log of that number, heaviest first, stable (the given
 //     leading-base order inside a class), and the search kernel takes queue position -> read from the result (BtArgs::order).
 #include <hip/hip_runtime.h>
@@ -43,11 +45,6 @@ __device__ __forceinline__ void echain_restart(const EffortArgs &a, EChain &c, b
 {
     c.k = 0; c.l = a.ix.seq_len; c.piece = 0; c.cl_n = 0; ++c.n_rs;
     if (lo_half) c.cost_lo += (uint32_t)a.c_restart; else c.cost_hi += (uint32_t)a.c_restart;
-}
-__device__ __forceinline__ void echain_indel(const EffortArgs &a, EChain &c, bool lo_half)
-{
-    c.k = 0; c.l = a.ix.seq_len; c.piece = 0; c.cl_n = 0; ++c.n_rs;
-    if (lo_half) c.cost_lo += (uint32_t)a.c_indel; else c.cost_hi += (uint32_t)a.c_indel;
 }
 // sym: the symbol the pattern grows by (0..3, 4 = N); cw: cost of finding text symbol t there instead (byte t); pos: read position of the base
 __device__ __forceinline__ void echain_step(const EffortArgs &a, EChain &c, int sym, uint32_t cw, int pos, bool lo_half, LaneStats &st)
@@ -70,14 +67,17 @@ __device__ __forceinline__ void echain_step(const EffortArgs &a, EChain &c, int 
     const int d = pos > c.cl_last ? pos - c.cl_last : c.cl_last - pos;
     if (c.cl_n > 0 && d <= 4) ++c.cl_n; else { c.cl_n = 1; c.cl_lo = c.cost_lo; c.cl_hi = c.cost_hi; }
     c.cl_last = pos;
-    if (c.cl_n >= 3) {              // an indel rather than three substitutions in a row: what the cluster was charged goes back, one restart instead
-        c.cost_lo = c.cl_lo; c.cost_hi = c.cl_hi;
-        echain_indel(a, c, lo_half);
+    if (lo_half) c.cost_lo += best_cost; else c.cost_hi += best_cost;
+    if (c.cl_n >= 3) {
+        // the third substitution within a few bases: an indel, a wrong locus, or really three differences in a row -- the read is
+        // (or may be) shifted against the text from here on and would pay a substitution per base.  The three stay charged (three real
+        // differences cost exactly that; an indel costs less, but a read that runs early costs nothing, and the 20 heaviest reads of
+        // the bench batch were of this kind and under-charged by a flat gap cost), the scan goes on with a new piece
+        c.k = 0; c.l = a.ix.seq_len; c.piece = 0; c.cl_n = 0; ++c.n_rs;
         return;
     }
     const bwtint b = L2_of(a.ix, best);
     c.k = b + sel4(ck, best) + 1; c.l = b + sel4(cl, best); ++c.piece;
-    if (lo_half) c.cost_lo += best_cost; else c.cost_hi += best_cost;
 }
 
 __global__ void __launch_bounds__(256) k_effort(EffortArgs a)
@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(256) k_effort(EffortArgs a)
         const uint32_t ta = A.cost_lo + A.cost_hi, tb = B.cost_lo + B.cost_hi;
         const uint32_t e = A.n_rs == 0 ? (B.n_rs == 0 && tb < ta ? tb : ta) : (B.n_rs == 0 ? tb : (ta > tb ? ta : tb));
         a.est[r] = (uint8_t)(e > 255u ? 255u : e);
-        if (a.est_ab) a.est_ab[r] = (uint16_t)((ta > 255u ? 255u : ta) | ((tb > 255u ? 255u : tb) << 8));
+        if (a.est_ab) a.est_ab[r] = (uint16_t)((ta > 127u ? 127u : ta) | (A.n_rs ? 0x80u : 0u) | ((tb > 127u ? 127u : tb) << 8) | (B.n_rs ? 0x8000u : 0u));     // profiling: totals, bit 7: the scan started over
     }
 }
 
@@ -144,6 +144,7 @@ __global__ void __launch_bounds__(256) k_effort_model(EffortModelArgs a)
             int D_im1 = 0;
             if (i > 0) { const uint32_t w2 = a.cwb[(size_t)((i - 1) >> 2) * a.n_reads + r]; D_im1 = (int)((w2 >> (8 * ((i - 1) & 3))) & 0x7fu); }
             const bool seed_chk = a.use_seed && len > a.seed_len && i > 0 && (i - (len - a.seed_len)) > 0;
+            const bool gap_here = a.max_gapo > 0 && i >= a.indel_end_skip && len - i >= a.indel_end_skip;
             phi_rows *= 0.25f;                                           // rows / 4^(d+1): expected random continuations of a string of d+1 symbols
             const float phi = phi_rows < 1.f ? phi_rows : 1.f;
             for (int u = 0; u <= B; ++u) Wn[u] = 0.f;
@@ -164,6 +165,10 @@ __global__ void __launch_bounds__(256) k_effort_model(EffortModelArgs a)
                     if (t == s) continue;
                     const int c = (int)((cw >> (8 * t)) & 0xffu);
                     if (u + c <= B) Wn[u + c] += wc;
+                }
+                if (gap_here) {                                          // gap openings (extensions and the gap states are not modelled)
+                    if (u + a.u_gapo_del <= B) Wn[u + a.u_gapo_del] += 4.f * wc;
+                    if (u + a.u_gapo_ins <= B) Wn[u + a.u_gapo_ins] += wc;
                 }
             }
             float *x = W; W = Wn; Wn = x;

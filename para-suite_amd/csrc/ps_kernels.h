@@ -26,9 +26,8 @@ struct EffortArgs {
     uint32_t s_pk[5];        // substitution costs as the search uses them (Model::s_mm_pk)
     int c_restart;           // charged where a scan has to start a new piece
     uint32_t w_pin;          // a substitution is believed where the interval is at most this wide (the scan has pinned its locus down)
-    int c_indel;             // charged where a cluster of substitutions is taken for an indel
     uint8_t *est;            // out: estimated score of the best hit, clipped to 255
-    uint16_t *est_ab;        // optional (profiling): the two scans' totals, byte each
+    uint16_t *est_ab;        // optional (profiling): the two scans' totals (7 bits each) and whether each had to start over (bit 7)
 };
 
 // expected search nodes of a read from its estimated final budget and its D(i) bounds (ps_effort.hip); out: the sort key of the hand-out order
@@ -39,6 +38,7 @@ struct EffortModelArgs {
     const uint8_t *est;
     uint32_t s_pk[5]; uint32_t inv_c_min;
     int max_units, u_tight, seed_units, use_seed, seed_len;
+    int max_gapo, indel_end_skip, u_gapo_ins, u_gapo_del;   // gap openings: one insertion child, four deletion children where the search allows an indel
     int depth;               // levels modelled (beyond ~19 symbols a random string no longer occurs in a genome of this size)
     float rows;              // BWT rows: a string of d symbols has min(1, rows / 4^d) expected occurrences
     int log_scale;           // key = 255 - log2(expected nodes) * log_scale

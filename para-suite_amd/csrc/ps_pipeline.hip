@@ -560,7 +560,6 @@ static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases
             if (const char *e = std::getenv("PS_ORDER_RESTART")) ea.c_restart = std::max(1, std::atoi(e));
             ea.w_pin = 16;
             if (const char *e = std::getenv("PS_ORDER_WPIN")) ea.w_pin = (uint32_t)std::max(1, std::atoi(e));
-            ea.c_indel = std::max(ea.c_restart, std::min(md.s_gapo_ins, md.s_gapo_del));
             int lv = 0; while (lv < 31 && (ctx->ix.view.seq_len >> (2 * lv)) > 0) ++lv;              // 4^lv > rows: 17 at hg19 size
             ea.est_ab = ctx->want_read_iters ? wk->ws_get<uint16_t>("est_ab", (size_t)n) : nullptr;
             launch_effort(ea, s);
@@ -577,6 +576,7 @@ static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases
                 for (int c = 0; c < 5; ++c) em.s_pk[c] = md.s_mm_pk[c];
                 em.inv_c_min = (uint32_t)md.inv_c_min; em.max_units = md.max_units; em.u_tight = md.u_tight;
                 em.seed_units = md.max_seed_diff * md.u_tight; em.use_seed = md.use_seed; em.seed_len = md.seed_len;
+                em.max_gapo = md.max_gapo; em.indel_end_skip = md.indel_end_skip; em.u_gapo_ins = md.u_gapo_ins; em.u_gapo_del = md.u_gapo_del;
                 em.depth = lv + 3; em.rows = (float)ctx->ix.view.seq_len; em.log_scale = 8;
                 if (const char *e = std::getenv("PS_ORDER_SCALE")) em.log_scale = std::max(1, std::min(12, std::atoi(e)));
                 if (d_lens) {                                             // ragged launch: every read's own budget, by its length

@@ -53,7 +53,9 @@ assert ri.shape[0] == n
 prof = np.empty_like(ri)
 prof[lib_order] = ri                                # now in input order
 it = prof[:, 0].astype(np.int64)
-estA = ((prof[:, 2] >> 16) & 0xff).astype(np.int64); estB = (prof[:, 2] >> 24).astype(np.int64); est = np.minimum(estA, estB); d_read = (prof[:, 2] & 0x7f).astype(np.int64); d_seed = ((prof[:, 2] >> 8) & 0x7f).astype(np.int64); 
+estA = ((prof[:, 2] >> 16) & 0x7f).astype(np.int64); estB = ((prof[:, 2] >> 24) & 0x7f).astype(np.int64); rsA = ((prof[:, 2] >> 23) & 1).astype(bool); rsB = ((prof[:, 2] >> 31) & 1).astype(bool)
+est = np.where(~rsA, np.where(~rsB & (estB < estA), estB, estA), np.where(~rsB, estB, np.maximum(estA, estB)))     # the library's rule (ps_effort.hip)
+d_read = (prof[:, 2] & 0x7f).astype(np.int64); d_seed = ((prof[:, 2] >> 8) & 0x7f).astype(np.int64); 
 best = (prof[:, 3] & 0xff).astype(np.int64); budget1 = ((prof[:, 3] >> 8) & 0xff).astype(np.int64); n_hits = (prof[:, 3] >> 16).astype(np.int64)
 print("iterations per read: mean %.0f, percentiles 50/90/99/99.9/max %s" % (it.mean(), np.percentile(it, [50, 90, 99, 99.9, 100]).astype(int).tolist()), flush=True)
 del b
@@ -80,7 +82,7 @@ for nm, f in (("est", est), ("min(est,16)", np.minimum(est, 16)), ("d_read", d_r
     print("corr(log iterations, %s) = %.3f" % (nm, np.corrcoef(np.log1p(it), f)[0, 1]))
 ns = min(n, 2_000_000)
 np.savez_compressed(outp + "_sample.npz", it=it[:ns].astype(np.uint32), d_read=d_read[:ns].astype(np.uint8), d_seed=d_seed[:ns].astype(np.uint8), best=best[:ns].astype(np.uint8),
-                    budget1=budget1[:ns].astype(np.uint8), estA=estA[:ns].astype(np.uint8), estB=estB[:ns].astype(np.uint8), cw=np.ascontiguousarray(prof[:ns, 4:17]).view(np.uint8).reshape(ns, 52), n_hits=n_hits[:ns].astype(np.uint16), reads=rd_h[:ns].astype(np.uint8))
+                    budget1=budget1[:ns].astype(np.uint8), estA=estA[:ns].astype(np.uint8), estB=estB[:ns].astype(np.uint8), rsA=rsA[:ns], rsB=rsB[:ns], cw=np.ascontiguousarray(prof[:ns, 4:17]).view(np.uint8).reshape(ns, 52), n_hits=n_hits[:ns].astype(np.uint16), reads=rd_h[:ns].astype(np.uint8))
 
 print("confusion: rows = true final budget, columns = min(est + 8, 24) (share of reads, %)")
 eb = np.minimum(est + 8, 24)
@@ -116,13 +118,8 @@ def classes_then_lib(cls):                  # heaviest class (largest value) fir
 # the library orders by leading bases itself (PS_KEEP_ORDER unset); PS_ORDER = its own effort order on top
 timed(None, "product, PS_ORDER=0", env={"PS_ORDER": "0"})
 timed(None, "PS_ORDER=1 (expected-nodes model, defaults)", env={"PS_ORDER": "1"})
-timed(None, "PS_ORDER=1 scale 4", env={"PS_ORDER": "1", "PS_ORDER_SCALE": "4"})
-timed(None, "PS_ORDER=1 scale 2", env={"PS_ORDER": "1", "PS_ORDER_SCALE": "2"})
-timed(None, "PS_ORDER=2 (estimated score only) cap 16", env={"PS_ORDER": "2", "PS_ORDER_CAP": "16"})
-timed(None, "product, PS_ORDER=0 again", env={"PS_ORDER": "0"})
 os.environ["PS_KEEP_ORDER"] = "1"          # from here on the library keeps the order it is given
 os.environ["PS_ORDER"] = "0"
-timed(classes_then_lib(budget1), "oracle: classes by TRUE final budget")
 q = np.searchsorted(np.quantile(it, np.arange(1, 8) / 8), it, side="right")
 timed(classes_then_lib(q), "oracle-8 (true counts, classes)")
 timed(np.argsort(-it, kind="stable"), "oracle-sort (longest first, no locality)")
