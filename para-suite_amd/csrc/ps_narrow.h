@@ -52,7 +52,8 @@ struct NLane {
     uint32_t nsb;                 // n_stack | bump<<16 (live entries; first never-used slot)
     uint32_t n_phantom;
     uint32_t fh;                  // free slot: the one popped last (0xffff: none)
-    unsigned long long bm0;       // non-empty score buckets (narrow tiers have at most 64)
+    uint32_t bm0, bm1;            // non-empty score buckets 0..31 / 32..63 (narrow tiers have at most 64; two words, not one 64-bit value: with <= 32
+                                  // buckets -- every default cost model -- the second word is never touched and costs no register moves)
     uint32_t rn0, rn1;            // N mask of a read of up to 64 bases (read orientation)
 };
 PS_HD int nl_best_score(const NLane &L) { return (int)(L.lim & 0xffu); }
@@ -64,7 +65,7 @@ PS_HD uint32_t nl_bump(const NLane &L) { return L.nsb >> 16; }
 PS_HD void nl_init(NLane &L)
 {
     L.kr = L.lr = L.wa = L.wb = 0; L.ctl = (uint32_t)M_FETCH; L.r = 0; L.lim = 0; L.nsb = 0;
-    L.n_phantom = 0; L.fh = 0xffffu; L.bm0 = 0; L.rn0 = L.rn1 = 0;
+    L.n_phantom = 0; L.fh = 0xffffu; L.bm0 = L.bm1 = 0; L.rn0 = L.rn1 = 0;
 }
 PS_HD void ls_init(LaneStats &st) { st.pairs = st.same = st.nodes = st.pushes = st.pops = st.iters = st.exact = st.lf = 0; }
 // 24-bit multiply (full rate on the device; the general 32-bit one runs at a quarter of it): for the small budget arithmetic
@@ -299,7 +300,7 @@ PS_COLD bool nt_fetch(const BtArgs &a, NLane &L, BtMem &m, int q)
     if (nNu > max_units) { nt_finish_read(a, L); return false; }
     L.kr = 0; L.lr = (uint32_t)a.ix.seq_len; L.wa = (uint32_t)len; L.wb = NW_ROOT_C << 6;     // the root: i = len, state M, score 0
     L.ctl |= NL_HAVE_CUR;
-    L.nsb = 0; L.bm0 = 0; L.fh = 0xffffu; L.n_phantom = 0;
+    L.nsb = 0; L.bm0 = L.bm1 = 0; L.fh = 0xffffu; L.n_phantom = 0;
     nt_heads_init(m, md.n_buckets);
     return true;
 }
@@ -320,13 +321,12 @@ PS_HD uint32_t nt_slot(NLane &L)
 PS_HD void nt_push(NLane &L, BtMem &m, uint32_t kr, uint32_t lr, uint32_t wa, uint32_t wb)
 {
     const int score = nw_score(wb);
-    const unsigned long long bit = 1ull << score;
     const uint32_t idx = nt_slot(L);
     const uint32_t next = (uint32_t)m.heads16[score];        // NIL while the bucket is empty (nt_heads_init, nt_pop)
     Entry16 e; e.k = kr; e.l = lr; e.a = wa; e.b = wb | (next << 16);
     store16(reinterpret_cast<Entry16 *>(m.pool) + idx, e);
     m.heads16[score] = (uint16_t)idx;
-    L.bm0 |= bit;
+    if (score < 32) L.bm0 |= 1u << score; else L.bm1 |= 1u << (score - 32);
 }
 
 // pop the newest entry of the lowest non-empty bucket into the lane's current-entry registers.  NB32: the cost model has at
@@ -336,9 +336,9 @@ template <bool NB32>
 PS_HD void nt_pop(NLane &L, BtMem &m)
 {
 #ifdef __HIP_DEVICE_COMPILE__
-    const int b = NB32 ? __ffs((int)(uint32_t)L.bm0) - 1 : __ffsll((unsigned long long)L.bm0) - 1;
+    const int b = (NB32 || L.bm0) ? __ffs((int)L.bm0) - 1 : 32 + __ffs((int)L.bm1) - 1;
 #else
-    const int b = __builtin_ctzll(L.bm0);
+    const int b = (NB32 || L.bm0) ? __builtin_ctz(L.bm0) : 32 + __builtin_ctz(L.bm1);
 #endif
     const uint32_t hd = m.heads16[b];
     Entry16 e;
@@ -346,7 +346,7 @@ PS_HD void nt_pop(NLane &L, BtMem &m)
     const uint32_t next = e.b >> 16;
     L.fh = hd;
     m.heads16[b] = (uint16_t)next;                           // NIL when this was the bucket's last entry
-    if (next == PS_NIL16) { if (NB32) L.bm0 = (uint32_t)L.bm0 & ~(1u << b); else L.bm0 &= ~(1ull << b); }
+    if (next == PS_NIL16) { if (NB32 || b < 32) L.bm0 &= ~(1u << b); else L.bm1 &= ~(1u << (b - 32)); }
     L.kr = e.k; L.lr = e.l; L.wa = e.a; L.wb = e.b & 0xffffu;
     L.nsb -= 1u;
 }
@@ -542,7 +542,7 @@ PS_HD void nt_tail(const BtHot &h, NLane &L, LaneStats &st, BtMem &m, const NtSt
             idx[j] = (reuse && rank == 0u) ? fr : slot0 + rank;
             raw[j] = m.heads16[sc[j]];
             m.heads16[sc[j]] = (uint16_t)idx[j];
-            if (NB32) L.bm0 = (uint32_t)L.bm0 | (1u << sc[j]); else L.bm0 |= 1ull << sc[j];
+            if (NB32 || sc[j] < 32) L.bm0 |= 1u << sc[j]; else L.bm1 |= 1u << (sc[j] - 32);
         }
     }
 #ifdef __HIP_DEVICE_COMPILE__

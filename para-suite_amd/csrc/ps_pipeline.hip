@@ -553,9 +553,11 @@ static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases
             int32_t *iota = wk->ws_get<int32_t>("oiota", (size_t)n), *order = wk->ws_get<int32_t>("order", (size_t)n);
             EffortArgs ea;
             ea.ix = ctx->ix.view; ea.n_reads = n; ea.len = len; ea.lens = d_lens; ea.bases = d_bases; ea.nmask = d_nmask; ea.est = est;
+            // everything here is in BUDGET UNITS (what the search's limits are in): the profile model has units == score, stock counts
+            // every difference as one unit whatever it scores
             int csum = 0;
-            for (int c = 0; c < 5; ++c) ea.s_pk[c] = md.s_mm_pk[c];
-            for (int sc = 0; sc < 4; ++sc) for (int tc = 0; tc < 4; ++tc) if (sc != tc) csum += md.s_mm[sc][tc];
+            for (int c = 0; c < 5; ++c) ea.s_pk[c] = md.u_mm_pk[c];
+            for (int sc = 0; sc < 4; ++sc) for (int tc = 0; tc < 4; ++tc) if (sc != tc) csum += md.u_mm[sc][tc];
             ea.c_restart = std::max(1, (csum + 6) / 12);                      // an average mismatch
             if (const char *e = std::getenv("PS_ORDER_RESTART")) ea.c_restart = std::max(1, std::atoi(e));
             ea.w_pin = 16;
@@ -573,7 +575,7 @@ static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases
             } else {
                 EffortModelArgs em;
                 em.n_reads = n; em.len = len; em.lens = d_lens; em.units_by_len = nullptr; em.bases = d_bases; em.nmask = d_nmask; em.cwb = cwb; em.est = est;
-                for (int c = 0; c < 5; ++c) em.s_pk[c] = md.s_mm_pk[c];
+                for (int c = 0; c < 5; ++c) em.s_pk[c] = md.u_mm_pk[c];
                 em.inv_c_min = (uint32_t)md.inv_c_min; em.max_units = md.max_units; em.u_tight = md.u_tight;
                 em.seed_units = md.max_seed_diff * md.u_tight; em.use_seed = md.use_seed; em.seed_len = md.seed_len;
                 em.max_gapo = md.max_gapo; em.indel_end_skip = md.indel_end_skip; em.u_gapo_ins = md.u_gapo_ins; em.u_gapo_del = md.u_gapo_del;

@@ -233,7 +233,7 @@ int hs_unit_rows33(void)
             nt_push(N, m, (uint32_t)k, (uint32_t)l, wa, wb);
             N.kr = N.lr = N.wa = N.wb = 0;
             nt_pop<false>(N, m);
-            if (N.kr != (uint32_t)k || N.lr != (uint32_t)l || N.wa != wa || N.wb != wb || nl_n_stack(N) != 0 || N.bm0 != 0) return 1;
+            if (N.kr != (uint32_t)k || N.lr != (uint32_t)l || N.wa != wa || N.wb != wb || nl_n_stack(N) != 0 || N.bm0 != 0 || N.bm1 != 0) return 1;
             if (nw_i(N.wa) != 17 || nw_ldp(N.wa) != 17 || nw_mm(N.wa) != 3 || nw_state(N.wa) != ST_D || nw_gapo(N.wa) != 2 || nw_gape(N.wa) != 5 ||
                 nw_ins(N.wb) != 7 || nw_del(N.wb) != 6 || nw_c(N.wb) != 3 || nw_score(N.wb) != 9) return 2;
             for (uint32_t c = 0; c < 4; ++c) if (nt_base(a, c) != a0.ix.L2[c]) return 8;

@@ -17,6 +17,8 @@ import numpy as np
 
 os.environ["PS_READ_ITERS"] = "1"
 os.environ["PS_ORDER"] = "1"            # the counting pass records the estimate the library orders by
+for kv in sys.argv[4:]:                  # further NAME=value settings for the library (e.g. PS_ORDER_WPIN=4)
+    os.environ[kv.split("=")[0]] = kv.split("=")[1]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "para-suite_amd"))
 import torch   # noqa: E402
@@ -117,7 +119,9 @@ def classes_then_lib(cls):                  # heaviest class (largest value) fir
 
 # the library orders by leading bases itself (PS_KEEP_ORDER unset); PS_ORDER = its own effort order on top
 timed(None, "product, PS_ORDER=0", env={"PS_ORDER": "0"})
-timed(None, "PS_ORDER=1 (expected-nodes model, defaults)", env={"PS_ORDER": "1"})
+timed(None, "PS_ORDER=1 (expected-nodes model, as set)", env={"PS_ORDER": "1"})
+if len(sys.argv) > 4:
+    raise SystemExit(0)
 os.environ["PS_KEEP_ORDER"] = "1"          # from here on the library keeps the order it is given
 os.environ["PS_ORDER"] = "0"
 q = np.searchsorted(np.quantile(it, np.arange(1, 8) / 8), it, side="right")
