@@ -547,7 +547,9 @@ static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases
     {
         const char *eo = std::getenv("PS_ORDER");
         const int mode = eo ? std::atoi(eo) : 1;
-        if (mode > 0 && n >= 4096) {
+        int min_n = 4096;                                     // below that every read has a lane to itself at once: no order to choose
+        if (const char *e = std::getenv("PS_ORDER_MIN")) min_n = std::max(1, std::atoi(e));      // tests: the small launches of the fuzz sweep too
+        if (mode > 0 && n >= min_n) {
             EvTimer t(s);
             uint8_t *est = wk->ws_get<uint8_t>("est", (size_t)n), *key = wk->ws_get<uint8_t>("okey", (size_t)n), *key2 = wk->ws_get<uint8_t>("okey2", (size_t)n);
             int32_t *iota = wk->ws_get<int32_t>("oiota", (size_t)n), *order = wk->ws_get<int32_t>("order", (size_t)n);
