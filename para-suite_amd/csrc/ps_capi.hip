@@ -57,6 +57,7 @@ static ps_ctx *new_ctx(int device)
     if (std::getenv("PS_KSTATS")) x->c.want_kstats = true;
     if (const char *e = std::getenv("PS_BT_BLOCKS")) x->c.bt_blocks = std::atoi(e);
     if (const char *e = std::getenv("PS_POOL_CAP")) x->c.pool_cap[0] = (uint32_t)std::atoi(e);
+    if (const char *e = std::getenv("PS_ALN_CAP")) x->c.aln_cap[0] = std::max(1, std::atoi(e));           // hit intervals a read may list in the first tier
     return x;
 }
 

@@ -36,11 +36,11 @@ static const uint32_t NW_KEEP = 0xFCFF0000u;       // of wa: n_mm and the gap co
 static const uint32_t NW_C_MASK = 7u << 6;
 static const uint32_t NW_ROOT_C = 4u;
 
-// lane control word: mode | have_cur<<3 | status<<4 | on_big<<6 | n_aln<<16
+// lane control word: mode | have_cur<<3 | status<<4 (3 bits) | on_big<<7 | n_aln<<16
 PS_HD int nl_mode(uint32_t ctl) { return (int)(ctl & 7u); }
 PS_HD uint32_t nl_set_mode(uint32_t ctl, int mode) { return (ctl & ~7u) | (uint32_t)mode; }
-static const uint32_t NL_HAVE_CUR = 8u, NL_STATUS = 3u << 4, NL_BIG = 1u << 6;
-PS_HD int nl_status(uint32_t ctl) { return (int)((ctl >> 4) & 3u); }
+static const uint32_t NL_HAVE_CUR = 8u, NL_STATUS = 7u << 4, NL_BIG = 1u << 7;
+PS_HD int nl_status(uint32_t ctl) { return (int)((ctl >> 4) & 7u); }
 PS_HD uint32_t nl_set_status(uint32_t ctl, int s) { return (ctl & ~NL_STATUS) | ((uint32_t)s << 4); }
 PS_HD int nl_n_aln(uint32_t ctl) { return (int)(ctl >> 16); }
 
@@ -448,7 +448,8 @@ PS_HD void nt_tail(const BtHot &h, NLane &L, LaneStats &st, BtMem &m, const NtSt
     const uint32_t cap = (L.ctl & NL_BIG) ? h.big_cap : h.pool_cap;
     if (nl_bump(L) + 9u > cap) {          // stack full: ask for a large slot once; if that is full too, the read goes to the next tier
         if (!(L.ctl & NL_BIG) && h.has_big()) { L.ctl = nl_set_mode(L.ctl, M_GROW); return; }
-        L.ctl = nl_set_mode(nl_set_status(L.ctl, RS_OVERFLOW_POOL), M_POP); return;
+        // a stack of 65,535 entries (a large slot, or the second tier's private one) is the deepest a 16-bit link reaches: straight to the wide tier
+        L.ctl = nl_set_mode(nl_set_status(L.ctl, cap >= 65535u ? RS_OVERFLOW_DEEP : RS_OVERFLOW_POOL), M_POP); return;
     }
     const int max_units = nl_max_units(L);
     const int e_un = nt_units(h, L.wa, L.wb), e_sc = nw_score(L.wb);

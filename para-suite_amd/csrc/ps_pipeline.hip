@@ -917,7 +917,14 @@ void batch_search(Batch &b)
             if (h_status[r] == RS_BAD_SCORE) throw Error("internal: score outside the bucket range");
             todo.push_back(r);
         }
-        for (int tier = 1; tier < 3 && !todo.empty(); ++tier) {          // reads that need a deeper stack / longer hit list
+        // reads that need a deeper stack / a longer hit list: the second narrow tier, then the wide one.  A read whose stack outgrew
+        // 65,535 entries already (RS_OVERFLOW_DEEP: on a large slot of the first launch) skips the second tier, which has no more than
+        // that: on a repeat-rich genome those are the longest searches of the batch, and every tier starts them from scratch
+        std::vector<int32_t> deep;
+        { std::vector<int32_t> keep; for (int32_t r : todo) (h_status[r] == RS_OVERFLOW_DEEP ? deep : keep).push_back(r); todo.swap(keep); }
+        for (int tier = 1; tier < 3; ++tier) {
+            if (tier == 2) { todo.insert(todo.end(), deep.begin(), deep.end()); std::sort(todo.begin(), todo.end()); deep.clear(); }
+            if (todo.empty()) continue;
             b.n_overflow[tier] += (int64_t)todo.size();
             const int m = (int)todo.size();
             std::vector<uint32_t> hb((size_t)bin.n_bw * m), hm((size_t)bin.n_mw * m);

@@ -80,7 +80,8 @@ struct AlnRec {
     uint8_t n_mm, n_gapo, n_gape, n_ins, n_del, pad[7];
 };  // 32 B
 
-enum { RS_OK = 0, RS_OVERFLOW_POOL = 1, RS_OVERFLOW_ALN = 2, RS_BAD_SCORE = 3 };
+enum { RS_OK = 0, RS_OVERFLOW_POOL = 1, RS_OVERFLOW_ALN = 2, RS_BAD_SCORE = 3,
+       RS_OVERFLOW_DEEP = 4 };   // the stack outgrew the largest narrow stack there is (65,535 entries: a large slot or the second tier): only the wide tier can hold it
 
 struct KStats {            // per-launch counters (roofline accounting)
     unsigned long long occ_pairs, occ_same_blk, nodes, pushes, pops, lf_steps, iters, exact_steps;
