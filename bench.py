@@ -477,13 +477,14 @@ def main():
             return out
         steps = [None] * n
         done = [False] * n
+        stagger = max(0.002, 0.05 * n_mine / 10e6)       # 50 ms behind a 10 M-read launch, in proportion for smaller batches
 
         def begin(k):
             if k >= PIPE and not done[k - PIPE]:
                 out_k = steps[k - PIPE].finish(); done[k - PIPE] = True      # the batch is free when its previous step is through
                 results[k - PIPE] = out_k
             if k > 0:
-                time.sleep(max(0.0, steps[k - 1].submitted + 0.05 - time.perf_counter()))
+                time.sleep(max(0.0, steps[k - 1].submitted + stagger - time.perf_counter()))
             steps[k] = Step(sets[k % PIPE]); steps[k].start()
         results = [None] * n
         try:

@@ -549,7 +549,7 @@ static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases
         const int mode = eo ? std::atoi(eo) : 1;
         int min_n = 4096;                                     // below that every read has a lane to itself at once: no order to choose
         if (const char *e = std::getenv("PS_ORDER_MIN")) min_n = std::max(1, std::atoi(e));      // tests: the small launches of the fuzz sweep too
-        if (mode > 0 && n >= min_n) {
+        if (mode > 0 && n >= min_n && md.max_units >= md.c_min) {      // a search that can afford no difference is ~len steps for every read: nothing to order
             EvTimer t(s);
             uint8_t *est = wk->ws_get<uint8_t>("est", (size_t)n), *key = wk->ws_get<uint8_t>("okey", (size_t)n), *key2 = wk->ws_get<uint8_t>("okey2", (size_t)n);
             int32_t *iota = wk->ws_get<int32_t>("oiota", (size_t)n), *order = wk->ws_get<int32_t>("order", (size_t)n);
