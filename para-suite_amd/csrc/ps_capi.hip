@@ -530,7 +530,13 @@ static int map_core(int threads, const char *mm, const char *error_profile, cons
             try {
                 Ctx &c = xs[g]->c;
                 require_device(c.device);
-                if (dev_workers[g] > 1) reserve_search_workspace(&c, j);   // several workers on one device: before any search kernel runs on it
+                // The worker's big allocations (69 GB of stack slices + the large slots) are made NOW, on a thread of their own, while the
+                // index loads and the parser works on the first piece: a hipMalloc that is handed memory another call or process has
+                // just freed waits for the driver to clear it (seconds for this size, tools/microbench_malloc) -- behind the index load
+                // that wait is hidden, in front of the first search launch (where the first ws_get used to make it) it is not.  With
+                // several workers on one device it also keeps a worker's allocation from waiting for another worker's running kernel.
+                std::thread reserve([&c, j]() { try { reserve_search_workspace(&c, j); } catch (...) {} });
+                struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } reserve_joiner{reserve};
                 if (j == 0) {                                          // this device's index: from the files, or from the first device
                     if (g == 0) { index_load(ref_fa, c.ix, c.stream); t_index = since(); }
                     else {
@@ -540,6 +546,7 @@ static int map_core(int threads, const char *mm, const char *error_profile, cons
                     { std::lock_guard<std::mutex> l(mu); index_state[g] = 1; t_index_all = since(); }
                     cv.notify_all();
                 } else { std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return failed || index_state[g] == 1; }); if (failed) return; }
+                if (reserve.joinable()) reserve.join();
                 Piece p;
                 while (parsed.pop(p)) {
                     { std::lock_guard<std::mutex> l(mu); if (failed) return; n_reads += p.b->rs.n; ++n_pieces; }
