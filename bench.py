@@ -283,9 +283,11 @@ def main():
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--penalty", choices=["profile", "stock"], default="profile", help="full workload: PAR-CLIP error-profile costs (bwa parasuite) or stock costs (bwa aln -n 0.04)")
     ap.add_argument("--sub-batches", type=int, default=1, help="2: the batch of a step is mapped as two halves on two lanes (streams) driven by two threads; measured slower than 1 (DESIGN.md section 5)")
-    ap.add_argument("--pipeline", type=int, default=2, help="batches in flight per GPU (1 or 2; 2 needs --sub-batches 1): with 2, consecutive steps alternate between two "
-                    "batches on two streams and the search launch of step k+1 is submitted while step k's still runs, so that it takes the CUs step k's "
-                    "retiring workgroups leave (tools/backfill_probe.py, tools/pipeline_probe.py)")
+    ap.add_argument("--pipeline", type=int, default=0, help="batches in flight per GPU (1 to 3; more than 1 needs --sub-batches 1): consecutive steps alternate between "
+                    "that many batches, each on its own stream with its own 69-GB workspace, and the search launch of step k+1 is submitted while step k's still runs, "
+                    "so that it takes the CUs step k's retiring workgroups leave (tools/backfill_probe.py, tools/pipeline_probe.py).  0 (default) = 2 for a rank "
+                    "with at least 4 M reads, 3 below that: a launch lasts at least as long as its longest search (~0.3 s, the `drain` block), and a small "
+                    "batch holds less work than that -- the ranks of an 8-GPU strong-scaling job")
     ap.add_argument("--e2e", type=int, default=1, help="N=1: also time one ps_map call, FASTQ file -> closed SAM file (the reference's own timer scope)")
     ap.add_argument("--dump-hits", default="", help="directory: every rank saves the per-read hit records of its last step (tests)")
     ap.add_argument("--keep", default="")
@@ -316,7 +318,7 @@ def main():
     threads = args.threads or min(16, max(1, (os.cpu_count() or 8) // max(1, world)))
     log = (lambda *a: print("[bench r%d]" % rank, *a, file=sys.stderr, flush=True))
     S = 2 if args.sub_batches >= 2 else 1
-    PIPE = 2 if (args.pipeline >= 2 and S == 1) else 1        # the context has two lanes of work (stream + workspace)
+    PIPE = 0                                                   # set below, once the rank's share of the reads is known
     do_e2e = bool(args.e2e) and world == 1
 
     # ---------------- data: genome on every rank (same seed), index built on rank 0 ----------------
@@ -378,6 +380,7 @@ def main():
     else:
         codes = gen_reads(torch, dev, contigs, args.reads, args.read_len, 0x5EED0003 + rank, indels=(args.workload == "full"))
     n_mine = codes.shape[0]
+    PIPE = 1 if S > 1 else max(1, min(3, args.pipeline if args.pipeline > 0 else (2 if n_mine >= 4_000_000 else 3)))     # lanes of work: stream + workspace each
     del contigs
     torch.cuda.empty_cache()
     # the batch of a step as S sub-batches (contiguous halves, input order) on S lanes: stream + workspace each
@@ -462,9 +465,9 @@ def main():
             return tms
 
     def run_steps(n):
-        """n steps, results in step order.  With PIPE == 2 consecutive steps alternate between the two batches: step k+1 is
-        started -- its search launch submitted -- as soon as its batch is free (step k-1 finished) and step k's launch has had the
-        GPU to itself for a moment (two launches submitted together share the CUs from the start), i.e. while step k's kernel
+        """n steps, results in step order.  With PIPE > 1 consecutive steps alternate between PIPE batches: step k+1 (.. k+PIPE-1) is
+        started -- its search launch submitted -- as soon as its batch is free (step k+1-PIPE finished) and the launch before it has
+        had the GPU to itself for a moment (two launches submitted together share the CUs from the start), i.e. while step k's kernel
         still runs: its workgroups start where step k's retire, and step k's short later stages run inside that hand-over."""
         out = []
         if PIPE == 1:
@@ -488,11 +491,10 @@ def main():
             steps[k] = Step(sets[k % PIPE]); steps[k].start()
         results = [None] * n
         try:
-            if n:
-                begin(0)
+            started = 0
             for k in range(n):
-                if k + 1 < n:
-                    begin(k + 1)
+                while started < min(n, k + PIPE):      # PIPE - 1 further steps are under way while step k takes its turn in the tie-break chain
+                    begin(started); started += 1
                 steps[k].chain()
             for k in range(n):
                 if not done[k]:

@@ -166,7 +166,7 @@ int ps_ctx_sa_lookup(ps_ctx *x, const uint64_t *rows, int64_t n, uint64_t *out)
 int ps_ctx_set_lanes(ps_ctx *x, int n)
 {
     PS_TRY
-        if (n < 1 || n > (int)Ctx::N_WORK) throw Error("lanes: 1 or 2");
+        if (n < 1 || n > (int)Ctx::N_WORK) throw Error("lanes: 1 to 4");
         x->c.n_work = n; return 0;
     PS_CATCH_INT
 }

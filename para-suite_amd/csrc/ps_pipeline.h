@@ -92,7 +92,7 @@ struct Ctx {
     int n_big = 4096;              // 1 MB stack slots a launch may hand to reads that outgrow their private slice
     int fetch_min = 8, hit_min = 1;    // batching hits costs more in idle lanes than it saves (measured)
     int host_threads = 8;
-    static const int N_WORK = 2;
+    static const int N_WORK = 4;
     std::unique_ptr<Work> work[N_WORK];
     int n_work = 1, next_work = 0; // lanes in use (1: every batch shares one workspace and stream); batches take them in turn
     Work *take_work();             // creates the lane's stream on first use
