@@ -285,9 +285,8 @@ def main():
     ap.add_argument("--sub-batches", type=int, default=1, help="2: the batch of a step is mapped as two halves on two lanes (streams) driven by two threads; measured slower than 1 (DESIGN.md section 5)")
     ap.add_argument("--pipeline", type=int, default=0, help="batches in flight per GPU (1 to 3; more than 1 needs --sub-batches 1): consecutive steps alternate between "
                     "that many batches, each on its own stream with its own 69-GB workspace, and the search launch of step k+1 is submitted while step k's still runs, "
-                    "so that it takes the CUs step k's retiring workgroups leave (tools/backfill_probe.py, tools/pipeline_probe.py).  0 (default) = 2 for a rank "
-                    "with at least 4 M reads, 3 below that: a launch lasts at least as long as its longest search (~0.3 s, the `drain` block), and a small "
-                    "batch holds less work than that -- the ranks of an 8-GPU strong-scaling job")
+                    "so that it takes the CUs step k's retiring workgroups leave (tools/backfill_probe.py, tools/pipeline_probe.py).  0 (default) = 2: three in "
+                    "flight were measured slower than two at every batch size (1.25 M reads: 280 against 232 ms per step; 10 M: 1230 against 1228)")
     ap.add_argument("--e2e", type=int, default=1, help="N=1: also time one ps_map call, FASTQ file -> closed SAM file (the reference's own timer scope)")
     ap.add_argument("--dump-hits", default="", help="directory: every rank saves the per-read hit records of its last step (tests)")
     ap.add_argument("--keep", default="")
@@ -380,7 +379,7 @@ def main():
     else:
         codes = gen_reads(torch, dev, contigs, args.reads, args.read_len, 0x5EED0003 + rank, indels=(args.workload == "full"))
     n_mine = codes.shape[0]
-    PIPE = 1 if S > 1 else max(1, min(3, args.pipeline if args.pipeline > 0 else (2 if n_mine >= 4_000_000 else 3)))     # lanes of work: stream + workspace each
+    PIPE = 1 if S > 1 else max(1, min(3, args.pipeline if args.pipeline > 0 else 2))     # lanes of work: stream + workspace each
     del contigs
     torch.cuda.empty_cache()
     # the batch of a step as S sub-batches (contiguous halves, input order) on S lanes: stream + workspace each
