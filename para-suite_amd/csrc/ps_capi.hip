@@ -420,6 +420,7 @@ static int map_core(int threads, const char *mm, const char *error_profile, cons
             }
         }
 
+        if (const char *e = std::getenv("PS_FIRST_MB")) first_bytes = (size_t)std::max(1, std::atoi(e)) << 20;      // first piece (the following ones double up to the piece size)
         struct Piece { int64_t seq = 0; std::unique_ptr<Batch> b; };
         Chan<Piece> parsed;
         parsed.cap = (size_t)std::max(2, n_workers);
@@ -443,6 +444,7 @@ static int map_core(int threads, const char *mm, const char *error_profile, cons
         auto fail_all = [&](const std::string &m) { { std::lock_guard<std::mutex> l(mu); if (!failed) { failed = true; msg = m; } } cv.notify_all(); parsed.abort(); };
         double t_parse = 0, t_write = 0, t_release = 0, t_index = 0, t_index_all = 0, t_profile = 0; std::vector<double> t_gpu((size_t)n_workers, 0.0);
         int64_t n_reads = 0, n_pieces = 0;
+        std::vector<std::thread> trash;                  // threads that free written pieces; joined at the end
         // ---- parser (starts at once)
         std::thread parser([&]() {
             try {
@@ -497,7 +499,7 @@ static int map_core(int threads, const char *mm, const char *error_profile, cons
                     { std::lock_guard<std::mutex> l(mu); ++write_next; }
                     cv.notify_all();
                     const auto t1 = std::chrono::steady_clock::now();
-                    b.reset();                                         // pinned record buffers, the reads: released here, not on the GPU worker's time
+                    { Batch *q = b.release(); std::lock_guard<std::mutex> l(mu); trash.emplace_back([q]() { delete q; }); }   // pinned record buffers, the reads (~40 ms per piece): released on a thread of its own, neither on the GPU worker's time nor on the writer's
                     t_release += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
                 }
                 if (first) {                      // no reads at all: the header alone, as upstream's samse prints it before its read loop
@@ -602,17 +604,24 @@ static int map_core(int threads, const char *mm, const char *error_profile, cons
         const double t_workers = since();
         cv.notify_all();
         parsed.abort();                           // a parser still waiting to hand over a piece must not wait forever
+        // The devices' memory (index, 69-GB workspaces: ~0.1 s of hipFree) goes back while the writer formats the last piece, which
+        // reads host memory only; the error-profile pass keeps its device (ProfileAccum counts on it until the writer is done).
+        std::thread early_release;
+        double t_release_dev = 0;
+        if (!sink) early_release = std::thread([&]() { for (ps_ctx *c : xs) if (c) { try { ctx_release_device(c->c); } catch (...) {} } t_release_dev = since(); });
         parser.join(); writer.join();
         const double t_written = since();
+        if (early_release.joinable()) early_release.join();
         done.clear();
         close_all();
+        for (auto &t : trash) t.join();
         const double t_closed = since();
         if (failed) return fail(msg);
         if (verbose) {
             double busy = 0; for (double v : t_gpu) busy += v;
             std::fprintf(stderr, "[parasuite-hip] ps_map: %lld reads in %lld piece(s) of <= %.0f MB, %d device(s) x %d worker(s), %.3f s; index resident after %.3f s (all devices %.3f s), "
-                                 "parser done after %.3f s, GPU stages busy %.3f s (summed over workers) and done after %.3f s, SAM writer busy %.3f s (+ %.3f s releasing pieces, %.3f s error profile) and done after %.3f s, contexts closed after %.3f s\n", (long long)n_reads, (long long)n_pieces, chunk_bytes / 1048576.0,
-                                 G, dev_workers[0], since(), t_index, t_index_all, t_parse, busy, t_workers, t_write, t_release, t_profile, t_written, t_closed);
+                                 "parser done after %.3f s, GPU stages busy %.3f s (summed over workers) and done after %.3f s, SAM writer busy %.3f s (+ %.3f s handing pieces back, %.3f s error profile) and done after %.3f s, device memory released after %.3f s, contexts closed after %.3f s\n", (long long)n_reads, (long long)n_pieces, chunk_bytes / 1048576.0,
+                                 G, dev_workers[0], since(), t_index, t_index_all, t_parse, busy, t_workers, t_write, t_release, t_profile, t_written, t_release_dev, t_closed);
         }
         return 0;
     PS_CATCH_INT

@@ -17,6 +17,9 @@
 #include <cstring>
 #include <fstream>
 #include <sstream>
+#include <mutex>
+#include <fcntl.h>
+#include <unistd.h>
 #include "ps_host.h"
 #include "ps_core.h"
 
@@ -607,35 +610,74 @@ template <class T> static void write_dev(const std::string &path, const char *ma
     ok = (std::fclose(f) == 0) && ok;
     if (!ok) throw Error("short write on " + path);
 }
-// file -> device through two pinned staging buffers: the next piece is read while the last one is on its way up
-// (a pageable 3.6 GB std::vector first cost 1.4 s for the hg19-size index)
-template <class T> static void read_dev(const std::string &path, const char *magic8, DevBuf<T> &d, hipStream_t s, std::vector<uint8_t> *host_copy = nullptr)
+// file -> device: a few reader threads, each with two pinned staging buffers, take 32-MB pieces of the file in turn (pread) and
+// send every piece up as soon as it is in -- the next one is read while the last is on its way.  One thread read ~12 GB/s out of the
+// page cache (0.37 s for the 4.7 GB of an hg19-size index, all of it in front of ps_map's first search launch); the bus takes four
+// times that.  (A pageable 3.6 GB std::vector first cost 1.4 s.)  The staging buffers come from the pinned-buffer cache of
+// ps_pipeline.hip and are shared by the three files of a load.
+void *pin_cache_take(size_t need, size_t &got);
+void pin_cache_give(void *p, size_t bytes);
+namespace {
+struct LoadStage {
+    static const size_t PIECE = (size_t)32 << 20;
+    int n_thr = 4, device = 0;
+    std::vector<void *> buf; std::vector<size_t> got; std::vector<hipEvent_t> done;
+    LoadStage()
+    {
+        if (const char *e = std::getenv("PS_LOAD_THREADS")) n_thr = std::max(1, std::min(16, std::atoi(e)));
+        PS_HIP(hipGetDevice(&device));
+        buf.assign((size_t)2 * n_thr, nullptr); got.assign((size_t)2 * n_thr, 0); done.assign((size_t)2 * n_thr, nullptr);
+    }
+    void ready(int slot)                              // buffers are taken by the thread that first needs them (a small file uses one or two)
+    {
+        if (!buf[slot]) { buf[slot] = pin_cache_take(PIECE, got[slot]); PS_HIP(hipEventCreateWithFlags(&done[slot], hipEventDisableTiming)); }
+    }
+    ~LoadStage() { for (size_t k = 0; k < buf.size(); ++k) { if (done[k]) (void)hipEventDestroy(done[k]); if (buf[k]) pin_cache_give(buf[k], got[k]); } }
+};
+}
+template <class T> static void read_dev(LoadStage &st, const std::string &path, const char *magic8, DevBuf<T> &d, hipStream_t s, std::vector<uint8_t> *host_copy = nullptr)
 {
-    FILE *f = std::fopen(path.c_str(), "rb");
-    if (!f) throw Error("cannot open " + path);
-    char mg[8]; uint64_t cnt = 0;
-    if (std::fread(mg, 1, 8, f) != 8 || std::memcmp(mg, magic8, 8) != 0 || std::fread(&cnt, 8, 1, f) != 1) { std::fclose(f); throw Error("bad header in " + path); }
-    try { d.alloc(cnt); } catch (...) { std::fclose(f); throw; }
-    const size_t total = (size_t)cnt * sizeof(T), PIECE = (size_t)64 << 20;
+    const int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) throw Error("cannot open " + path);
+    struct Closer { int fd; ~Closer() { ::close(fd); } } closer{fd};
+    char head[16]; uint64_t cnt = 0;
+    if (::pread(fd, head, 16, 0) != 16 || std::memcmp(head, magic8, 8) != 0) throw Error("bad header in " + path);
+    std::memcpy(&cnt, head + 8, 8);
+    d.alloc(cnt);
+    const size_t total = (size_t)cnt * sizeof(T), PIECE = LoadStage::PIECE, n_pieces = (total + PIECE - 1) / PIECE;
     if (host_copy) host_copy->resize(total);
-    struct Stage {                                   // released on every way out (a PS_HIP below may throw)
-        void *buf[2] = {nullptr, nullptr}; hipEvent_t done[2] = {nullptr, nullptr}; FILE *f;
-        explicit Stage(FILE *f_) : f(f_) {}
-        ~Stage() { for (int j = 0; j < 2; ++j) { if (buf[j]) (void)hipHostFree(buf[j]); if (done[j]) (void)hipEventDestroy(done[j]); } if (f) std::fclose(f); }
-    } st(f);
-    for (int k = 0; k < 2; ++k) { PS_HIP(hipHostMalloc(&st.buf[k], PIECE, hipHostMallocDefault)); PS_HIP(hipEventCreateWithFlags(&st.done[k], hipEventDisableTiming)); }
-    bool ok = true; size_t at = 0; int k = 0; bool used[2] = {false, false};
-    while (at < total && ok) {
-        const size_t m = std::min(PIECE, total - at);
-        if (used[k]) PS_HIP(hipEventSynchronize(st.done[k]));         // the copy that last used this buffer has finished
-        ok = std::fread(st.buf[k], 1, m, f) == m;
-        if (!ok) break;
-        if (host_copy) std::memcpy(host_copy->data() + at, st.buf[k], m);
-        PS_HIP(hipMemcpyAsync(reinterpret_cast<uint8_t *>(d.p) + at, st.buf[k], m, hipMemcpyHostToDevice, s));
-        PS_HIP(hipEventRecord(st.done[k], s)); used[k] = true;
-        at += m; k ^= 1;
+    std::atomic<size_t> next{0}; std::atomic<bool> ok{true};
+    std::mutex err_mu; std::string err;
+    auto reader = [&](int t) {
+        try {
+            PS_HIP(hipSetDevice(st.device));
+            int k = 0; bool used[2] = {false, false};
+            for (;;) {
+                const size_t i = next.fetch_add(1);
+                if (i >= n_pieces || !ok) break;
+                const int slot = 2 * t + k;
+                st.ready(slot);
+                if (used[k]) PS_HIP(hipEventSynchronize(st.done[slot]));      // the copy that last used this buffer has finished
+                const size_t at = i * PIECE, m = std::min(PIECE, total - at);
+                size_t have = 0;
+                while (have < m) { const ssize_t r = ::pread(fd, (char *)st.buf[slot] + have, m - have, (off_t)(16 + at + have)); if (r <= 0) break; have += (size_t)r; }
+                if (have != m) { ok = false; break; }
+                if (host_copy) std::memcpy(host_copy->data() + at, st.buf[slot], m);
+                PS_HIP(hipMemcpyAsync(reinterpret_cast<uint8_t *>(d.p) + at, st.buf[slot], m, hipMemcpyHostToDevice, s));
+                PS_HIP(hipEventRecord(st.done[slot], s)); used[k] = true;
+                k ^= 1;
+            }
+            for (int q = 0; q < 2; ++q) if (used[q]) PS_HIP(hipEventSynchronize(st.done[2 * t + q]));
+        } catch (const std::exception &e) { std::lock_guard<std::mutex> l(err_mu); if (err.empty()) err = e.what(); ok = false; }
+    };
+    {
+        const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)st.n_thr, n_pieces));
+        std::vector<std::thread> th; for (int t = 1; t < nt; ++t) th.emplace_back(reader, t);
+        reader(0);
+        for (auto &x : th) x.join();
     }
     PS_HIP(hipStreamSynchronize(s));
+    if (!err.empty()) throw Error(err);
     if (!ok) throw Error("truncated " + path);
 }
 
@@ -655,9 +697,10 @@ void index_load(const std::string &prefix, Index &ix, hipStream_t s)
     if (!a.good()) throw Error("cannot open " + prefix + ".ann (run ps_index first)");
     std::stringstream ss; ss << a.rdbuf();
     index_meta_deserialize(ss.str(), ix);
-    read_dev(prefix + ".bwt", MAGIC_BWT, ix.blocks, s);
-    read_dev(prefix + ".sa", "PSSA0002", ix.sa, s);
-    read_dev(prefix + ".pac", "PSPAC001", ix.pac, s, &ix.ref.pac);        // the host keeps the pac too (MD tags)
+    LoadStage st;
+    read_dev(st, prefix + ".bwt", MAGIC_BWT, ix.blocks, s);
+    read_dev(st, prefix + ".sa", "PSSA0002", ix.sa, s);
+    read_dev(st, prefix + ".pac", "PSPAC001", ix.pac, s, &ix.ref.pac);    // the host keeps the pac too (MD tags)
     bwtint primary = ix.view.primary; bwtint L2[5]; std::memcpy(L2, ix.view.L2, sizeof L2);
     ix.refresh_view();
     ix.view.primary = primary; std::memcpy(ix.view.L2, L2, sizeof L2);
@@ -671,7 +714,8 @@ void index_load_pac(const std::string &prefix, Index &ix, hipStream_t s)
     if (!a.good()) throw Error("cannot open " + prefix + ".ann (run ps_index first)");
     std::stringstream ss; ss << a.rdbuf();
     index_meta_deserialize(ss.str(), ix);
-    read_dev(prefix + ".pac", "PSPAC001", ix.pac, s, nullptr);
+    LoadStage st;
+    read_dev(st, prefix + ".pac", "PSPAC001", ix.pac, s, nullptr);
     ix.view.pac = ix.pac.p; ix.view.l_pac = (bwtint)ix.ref.l_pac;
 }
 

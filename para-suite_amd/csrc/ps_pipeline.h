@@ -151,6 +151,7 @@ void batch_upload(Batch &b);                                                  //
 void batch_search(Batch &b);                                    // width + backtracking kernels (+ larger tiers), hit lists to host
 void batch_select_hard(Batch &b, uint64_t draws_before, uint64_t *draws_after);
 void batch_select_easy(Batch &b, int threads);
+void ctx_release_device(Ctx &c);                               // every device allocation of the context (index blobs, lanes of work) freed; host-side reference data stays
 void reserve_search_workspace(Ctx *ctx, int work_index);        // the big device allocations of a lane of work, ahead of its first search
 void batch_locate(Batch &b);                                    // SA walk kernel, strand / MAPQ, banded DP of gapped hits
 void batch_bam_records(const Batch &b, int min_mapq, int threads, std::vector<std::string> &enc, std::vector<std::vector<BamRec>> &recs);   // the located batch as BAM records (MAPQ >= min_mapq): one buffer per thread, buffers in input order

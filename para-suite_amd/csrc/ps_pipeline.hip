@@ -40,6 +40,15 @@ void require_device(int device)
 }
 
 Ctx::~Ctx() { if (ref_event) (void)hipEventDestroy(ref_event); if (stream) (void)hipStreamDestroy(stream); }
+void ctx_release_device(Ctx &c)
+{
+    require_device(c.device);
+    {
+        std::lock_guard<std::mutex> l(c.work_mu);
+        for (auto &w : c.work) w.reset();
+    }
+    c.ix.blocks.release(); c.ix.sa.release(); c.ix.pac.release(); c.ix.jump.release();     // the view keeps its (now dangling) device pointers: nothing may search with this context again
+}
 Work *Ctx::work_at(int w)
 {
     std::lock_guard<std::mutex> l(work_mu);
@@ -247,13 +256,16 @@ static std::vector<size_t> cut_records(const char *b, size_t lo, size_t hi, int 
     cut.push_back(hi);
     return cut;
 }
+static double g_t_fread = 0, g_t_cut = 0, g_t_par = 0, g_t_merge = 0;   // PS_VERBOSE >= 2: where the parser's time goes
 // parse [lo, hi) of the file image on `threads` threads
 static void parse_span(const char *b, size_t lo, size_t hi, int threads, ReadSet &rs)
 {
     if (threads < 1) threads = 1;
     if (threads > 64) threads = 64;
+    const auto tc0 = std::chrono::steady_clock::now();
     const std::vector<size_t> cut = cut_records(b, lo, hi, threads);
     const int parts = (int)cut.size() - 1;
+    const auto tc1 = std::chrono::steady_clock::now();
     std::vector<ReadSet> piece((size_t)parts);
     std::vector<char> anyq((size_t)parts, 0);
     auto work = [&](int t) {
@@ -267,6 +279,9 @@ static void parse_span(const char *b, size_t lo, size_t hi, int threads, ReadSet
     for (int t = 1; t < parts; ++t) th.emplace_back(work, t);
     work(0);
     for (auto &x : th) x.join();
+    const auto tc2 = std::chrono::steady_clock::now();
+    g_t_cut += std::chrono::duration<double>(tc1 - tc0).count(); g_t_par += std::chrono::duration<double>(tc2 - tc1).count();
+    struct AtExit { std::chrono::steady_clock::time_point t; ~AtExit() { g_t_merge += std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); } } at_exit{tc2};
     if (parts == 1) { rs = std::move(piece[0]); rs.has_qual = anyq[0] != 0; return; }
     rs = ReadSet();
     size_t tn = 0, ts = 0, tq = 0, tnm = 0;
@@ -322,11 +337,13 @@ void load_reads_chunked(const char *path, int threads, size_t chunk_bytes, const
     while (!eof || have) {
         size_t want = cur > have ? cur : have + cur;      // grow when the carry-over alone fills a window
         buf.resize(want + 1);
+        const auto tr0 = std::chrono::steady_clock::now();
         while (!eof && have < want) {
             const size_t got = std::fread(buf.data() + have, 1, want - have, f);
             if (got == 0) { if (std::ferror(f)) throw Error(std::string("read error on ") + path); eof = true; }
             have += got;
         }
+        g_t_fread += std::chrono::duration<double>(std::chrono::steady_clock::now() - tr0).count();
         if (!mark && have) mark = buf[0];
         size_t cut = have;
         if (!eof) {
@@ -346,6 +363,9 @@ void load_reads_chunked(const char *path, int threads, size_t chunk_bytes, const
         have -= cut;
         if (eof && cut == 0) break;
     }
+    if (const char *e = std::getenv("PS_VERBOSE")) if (std::atoi(e) >= 2)
+        std::fprintf(stderr, "[parasuite-hip]     parser: reading %.0f ms, cutting %.0f ms, parsing on %d threads %.0f ms, joining the threads' parts %.0f ms (sums over the pieces)\n", 1e3 * g_t_fread, 1e3 * g_t_cut, threads, 1e3 * g_t_par, 1e3 * g_t_merge);
+    g_t_fread = g_t_cut = g_t_par = g_t_merge = 0;
 }
 
 void reads_from_codes(int64_t n, int len, const uint8_t *codes, ReadSet &rs)
@@ -1395,11 +1415,6 @@ static void put_int(std::string &o, long v)            // a dozen numbers per SA
     if (v < 0) b[--n] = '-';
     o.append(b + n, (size_t)(24 - n));
 }
-static void put_cigar(std::string &o, int n, const uint32_t *c, int len)
-{
-    if (n) for (int j = 0; j < n; ++j) { put_int(o, c[j] >> 4); o.push_back("MIDS"[c[j] & 0xf]); }
-    else { put_int(o, len); o.push_back('M'); }
-}
 static int64_t ref_span(int n, const uint32_t *c, int len)
 {
     if (!n) return len;
@@ -1432,8 +1447,41 @@ static void cal_md(const RefSeq &ref, int n_cigar, const uint32_t *cigar, int le
     put_int(md, u);
 }
 
+// SAM text goes through a raw cursor into storage the caller has made large enough (Room): a line is ~35 small pieces, and one
+// std::string append per piece was most of the 1.3 us per read and thread that the writer -- the last stage of ps_map -- spent.
+namespace {
+struct Cur {
+    char *p;
+    inline void ch(char c) { *p++ = c; }
+    inline void mem(const char *s, size_t n) { std::memcpy(p, s, n); p += n; }
+    template <size_t N> inline void lit(const char (&s)[N]) { std::memcpy(p, s, N - 1); p += N - 1; }
+    inline void num(long v)
+    {
+        static const char D2[] = "00010203040506070809101112131415161718192021222324252627282930313233343536373839404142434445464748495051525354555657585960616263646566676869707172737475767778798081828384858687888990919293949596979899";
+        unsigned long u = (unsigned long)v;
+        if (v < 0) { *p++ = '-'; u = 0ul - u; }
+        if (u < 10) { *p++ = (char)('0' + u); return; }
+        if (u < 100) { std::memcpy(p, D2 + 2 * u, 2); p += 2; return; }
+        char b[24]; int n = 24;
+        while (u >= 100) { const unsigned long r = u % 100; u /= 100; n -= 2; std::memcpy(b + n, D2 + 2 * r, 2); }
+        if (u >= 10) { n -= 2; std::memcpy(b + n, D2 + 2 * u, 2); } else b[--n] = (char)('0' + u);
+        std::memcpy(p, b + n, (size_t)(24 - n)); p += 24 - n;
+    }
+    inline void cigar(int n, const uint32_t *c, int len)
+    {
+        if (n) for (int j = 0; j < n; ++j) { num((long)(c[j] >> 4)); ch("MIDS"[c[j] & 0xf]); }
+        else { num(len); ch('M'); }
+    }
+};
+// storage with `used` bytes taken: at least `need` more, the string's size being the storage (grown in large steps, never shrunk here)
+inline char *room(std::string &o, size_t used, size_t need)
+{
+    if (o.size() < used + need) o.resize(std::max(o.size() + o.size() / 2, used + need + ((size_t)1 << 16)));
+    return &o[0] + used;
+}
+}
 // the XA list of a read (alternative hits, `samse -n 3`): chr,(+|-)pos,CIGAR,NM;
-static void xa_text(const Batch &b, const Hit &h, int len, std::string &o)
+static void xa_cur(const Batch &b, const Hit &h, int len, std::string &o, size_t &used)
 {
     const RefSeq &ref = b.ctx->ix.ref;
     for (int j = 0; j < h.n_multi; ++j) {
@@ -1441,13 +1489,23 @@ static void xa_text(const Batch &b, const Hit &h, int len, std::string &o)
         int sid = 0;
         ref.cnt_ambi(m.pos, (int)ref_span(m.n_cigar, m.cigar, len), &sid);
         const Contig &mc = ref.contigs[sid];
-        o.append(mc.name); o.push_back(','); o.push_back(m.strand ? '-' : '+'); put_int(o, (long)(m.pos - mc.offset + 1)); o.push_back(',');
-        put_cigar(o, m.n_cigar, m.cigar, len);
-        o.push_back(','); put_int(o, m.gap + m.mm); o.push_back(';');
+        Cur c{room(o, used, mc.name.size() + 64 + 12 * (size_t)PS_MAX_CIGAR)};
+        char *const c0 = c.p;
+        c.mem(mc.name.data(), mc.name.size()); c.ch(','); c.ch(m.strand ? '-' : '+'); c.num((long)(m.pos - mc.offset + 1)); c.ch(',');
+        c.cigar(m.n_cigar, m.cigar, len);
+        c.ch(','); c.num(m.gap + m.mm); c.ch(';');
+        used += (size_t)(c.p - c0);
     }
 }
+static void xa_text(const Batch &b, const Hit &h, int len, std::string &o)        // appended to a string (the BAM route)
+{
+    size_t used = o.size();
+    xa_cur(b, h, len, o, used);
+    o.resize(used);
+}
 
-static void sam_line(const Batch &b, int64_t g, std::string &o)
+// one line at o[used...]; `used` moves on.  o.size() is storage, not content (room()).
+static void sam_line(const Batch &b, int64_t g, std::string &o, size_t &used)
 {
     const ReadSet &rs = b.rs; const RefSeq &ref = b.ctx->ix.ref; const Options &opt = b.ctx->opt;
     Hit h; b.hit_of(g, h);
@@ -1455,48 +1513,59 @@ static void sam_line(const Batch &b, int64_t g, std::string &o)
     const uint8_t *seq = rs.seq.data() + rs.off[g];
     const char *qual = rs.has_qual ? rs.qual.data() + rs.off[g] : nullptr;
     size_t nl; const char *nm_ = rs.name(g, nl);
-    o.append(nm_, nl);
+    int seqid = 0, nn = 0, span = 0;
+    const Contig *ct = nullptr;
+    if (h.type != 0) {
+        span = (int)ref_span(h.n_cigar, h.cigar, len);
+        nn = ref.cnt_ambi(h.pos, span, &seqid);
+        ct = &ref.contigs[seqid];
+    }
+    // oriented read for MD/NM
+    static thread_local std::string md; int nm = 0;
+    if (h.type != 0) {
+        uint8_t tmp_small[256]; std::vector<uint8_t> tmp_big;
+        uint8_t *tmp = tmp_small;
+        if (len > 256) { tmp_big.resize((size_t)len); tmp = tmp_big.data(); }
+        const uint8_t *oriented = seq;
+        if (h.strand) { for (int i = 0; i < len; ++i) { uint8_t c = seq[len - 1 - i]; tmp[i] = c > 3 ? c : (uint8_t)(3 - c); } oriented = tmp; }
+        md.clear();
+        cal_md(ref, h.n_cigar, h.cigar, len, h.pos, oriented, md, nm);
+    }
+    // everything but the XA list: name, 11 columns (two of them the read), at most 9 tags of <= 26 characters, MD
+    Cur c{room(o, used, nl + 2 * (size_t)len + (ct ? ct->name.size() + md.size() : 0) + 12 * (size_t)PS_MAX_CIGAR + 384)};
+    char *const c0 = c.p;
+    c.mem(nm_, nl);
     auto put_seq = [&](int strand) {
-        const size_t at = o.size();
-        o.resize(at + (size_t)len + 1 + (qual ? (size_t)len : 1));
-        char *d = &o[at];
+        char *d = c.p;
         if (!strand) for (int i = 0; i < len; ++i) d[i] = "ACGTN"[seq[i]];
         else for (int i = 0; i < len; ++i) d[i] = "TGCAN"[seq[len - 1 - i]];
         d[len] = '\t';
         d += len + 1;
-        if (qual) { if (!strand) std::memcpy(d, qual, (size_t)len); else for (int i = 0; i < len; ++i) d[i] = qual[len - 1 - i]; }
-        else d[0] = '*';
+        if (qual) { if (!strand) std::memcpy(d, qual, (size_t)len); else for (int i = 0; i < len; ++i) d[i] = qual[len - 1 - i]; d += len; }
+        else *d++ = '*';
+        c.p = d;
     };
-    if (h.type == 0) { o.append("\t4\t*\t0\t0\t*\t*\t0\t0\t"); put_seq(h.strand); o.push_back('\n'); return; }
-    int seqid = 0, flag = 0;
-    const int span = (int)ref_span(h.n_cigar, h.cigar, len);
-    const int nn = ref.cnt_ambi(h.pos, span, &seqid);
-    const Contig &ct = ref.contigs[seqid];
-    if (h.pos + span - ct.offset > ct.len) flag |= 4;      // bridges two reference sequences
+    if (h.type == 0) { c.lit("\t4\t*\t0\t0\t*\t*\t0\t0\t"); put_seq(h.strand); c.ch('\n'); used += (size_t)(c.p - c0); return; }
+    int flag = 0;
+    if (h.pos + span - ct->offset > ct->len) flag |= 4;      // bridges two reference sequences
     if (h.strand) flag |= 16;
-    o.push_back('\t'); put_int(o, flag); o.push_back('\t'); o.append(ct.name); o.push_back('\t');
-    put_int(o, (long)(h.pos - ct.offset + 1)); o.push_back('\t'); put_int(o, h.mapq); o.push_back('\t');
-    put_cigar(o, h.n_cigar, h.cigar, len);
-    o.append("\t*\t0\t0\t");
+    c.ch('\t'); c.num(flag); c.ch('\t'); c.mem(ct->name.data(), ct->name.size()); c.ch('\t');
+    c.num((long)(h.pos - ct->offset + 1)); c.ch('\t'); c.num(h.mapq); c.ch('\t');
+    c.cigar(h.n_cigar, h.cigar, len);
+    c.lit("\t*\t0\t0\t");
     put_seq(h.strand);
-    // oriented read for MD/NM
-    uint8_t tmp_small[256]; std::vector<uint8_t> tmp_big;
-    uint8_t *tmp = tmp_small;
-    if (len > 256) { tmp_big.resize((size_t)len); tmp = tmp_big.data(); }
-    const uint8_t *oriented = seq;
-    if (h.strand) { for (int i = 0; i < len; ++i) { uint8_t c = seq[len - 1 - i]; tmp[i] = c > 3 ? c : (uint8_t)(3 - c); } oriented = tmp; }
-    static thread_local std::string md; md.clear(); int nm = 0;
-    cal_md(ref, h.n_cigar, h.cigar, len, h.pos, oriented, md, nm);
     char XT = "NURM"[h.type];
     if (nn > 10) XT = 'N';
-    o.append("\tXT:A:"); o.push_back(XT); o.append("\tNM:i:"); put_int(o, nm);
-    if (nn) { o.append("\tXN:i:"); put_int(o, nn); }
-    o.append("\tX0:i:"); put_int(o, h.c1);
-    if (h.c1 <= opt.max_top2) { o.append("\tX1:i:"); put_int(o, h.c2); }
-    o.append("\tXM:i:"); put_int(o, h.n_mm); o.append("\tXO:i:"); put_int(o, h.n_gapo); o.append("\tXG:i:"); put_int(o, h.n_gapo + h.n_gape);
-    o.append("\tMD:Z:"); o.append(md);
-    if (h.n_multi) { o.append("\tXA:Z:"); xa_text(b, h, len, o); }
-    o.push_back('\n');
+    c.lit("\tXT:A:"); c.ch(XT); c.lit("\tNM:i:"); c.num(nm);
+    if (nn) { c.lit("\tXN:i:"); c.num(nn); }
+    c.lit("\tX0:i:"); c.num(h.c1);
+    if (h.c1 <= opt.max_top2) { c.lit("\tX1:i:"); c.num(h.c2); }
+    c.lit("\tXM:i:"); c.num(h.n_mm); c.lit("\tXO:i:"); c.num(h.n_gapo); c.lit("\tXG:i:"); c.num(h.n_gapo + h.n_gape);
+    c.lit("\tMD:Z:"); c.mem(md.data(), md.size());
+    if (h.n_multi) c.lit("\tXA:Z:");
+    used += (size_t)(c.p - c0);
+    if (h.n_multi) xa_cur(b, h, len, o, used);
+    *room(o, used, 1) = '\n'; ++used;
 }
 
 // ---- the same record as a BAM record (ps_map_to_bam: no SAM text in between).  Field for field what sam_line prints and
@@ -1691,29 +1760,40 @@ void batch_write_sam(Batch &b, const char *path, bool header, const char *pg_lin
     const int64_t chunk = 1 << 16;
     std::vector<std::string> bufs[2] = {std::vector<std::string>((size_t)threads), std::vector<std::string>((size_t)threads)};
     std::vector<off_t> where[2] = {std::vector<off_t>((size_t)threads, 0), std::vector<off_t>((size_t)threads, 0)};
+    std::vector<size_t> lens[2] = {std::vector<size_t>((size_t)threads, 0), std::vector<size_t>((size_t)threads, 0)};
     std::thread io; std::atomic<bool> io_ok{true};
     const int n_io = std::max(1, std::min(4, threads));
     int which = 0;
+    static const bool verbose = std::getenv("PS_VERBOSE") != nullptr && std::atoi(std::getenv("PS_VERBOSE")) >= 2;
+    double t_fmt = 0, t_wait = 0; const auto tw0 = std::chrono::steady_clock::now();
     for (int64_t base = 0; base < N; base += chunk * threads, which ^= 1) {
+        const auto tf0 = std::chrono::steady_clock::now();
         std::vector<std::string> &out = bufs[which];          // the I/O threads may still hold the other set
+        std::vector<size_t> &used = lens[which];
         auto fmt = [&](int t) {
             int64_t g0 = base + chunk * t, g1 = std::min(N, g0 + chunk);
-            std::string &o = out[t];
-            o.clear();
-            if (g0 < g1) o.reserve((size_t)(g1 - g0) * 256);
-            for (int64_t g = g0; g < g1; ++g) sam_line(b, g, o);
+            std::string &o = out[t];                           // storage: its size is what it can hold, used[t] what it does hold
+            size_t u = 0;
+            if (g0 < g1) room(o, 0, (size_t)(g1 - g0) * 224);
+            for (int64_t g = g0; g < g1; ++g) sam_line(b, g, o, u);
+            used[t] = u;
         };
         { std::vector<std::thread> th; for (int t = 1; t < threads; ++t) th.emplace_back(fmt, t); fmt(0); for (auto &x : th) x.join(); }
+        const auto tf1 = std::chrono::steady_clock::now();
         if (io.joinable()) io.join();
+        t_fmt += std::chrono::duration<double>(tf1 - tf0).count(); t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - tf1).count();
         if (!io_ok) break;
         std::vector<off_t> &wh = where[which];
-        for (int t = 0; t < threads; ++t) { wh[t] = at; at += (off_t)out[t].size(); }
-        io = std::thread([&out, &wh, &put, &io_ok, n_io, threads]() {
-            auto part = [&](int k) { for (int t = k; t < threads; t += n_io) if (!out[t].empty() && !put(out[t].data(), out[t].size(), wh[t])) io_ok = false; };
+        for (int t = 0; t < threads; ++t) { wh[t] = at; at += (off_t)used[t]; }
+        io = std::thread([&out, &wh, &used, &put, &io_ok, n_io, threads]() {
+            auto part = [&](int k) { for (int t = k; t < threads; t += n_io) if (used[t] && !put(out[t].data(), used[t], wh[t])) io_ok = false; };
             std::vector<std::thread> th; for (int k = 1; k < n_io; ++k) th.emplace_back(part, k); part(0); for (auto &x : th) x.join();
         });
     }
+    const auto tl0 = std::chrono::steady_clock::now();
     if (io.joinable()) io.join();
+    if (verbose) std::fprintf(stderr, "[parasuite-hip]     SAM text of %lld reads: %.0f ms (formatting on %d threads %.0f ms, waiting for the previous round's pwrite %.0f ms, last round's pwrite %.0f ms), %.0f MB\n", (long long)N,
+                              1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - tw0).count(), threads, 1e3 * t_fmt, 1e3 * t_wait, 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - tl0).count(), at / 1048576.0);
     if (!io_ok) throw Error(std::string("short write on ") + path);
     closer.done = true;
     if (::close(fd) != 0) throw Error(std::string("cannot close ") + path);

@@ -24,13 +24,15 @@ with open('/tmp/e2e.errorprofile', 'w') as f:
     for row in P: f.write(''.join(repr(float(v)) + '\t' for v in row) + '\n')
 open('/tmp/e2e.indelprofile', 'w').write('2.1E-5\t5.9E-4')
 workers = [int(x) for x in sys.argv[3].split(',')] if len(sys.argv) > 3 else [1]      # PS_WORKERS_PER_GPU settings to time
-for kv in sys.argv[5:]:                                                                # further NAME=value settings for the library
-    os.environ[kv.split('=')[0]] = kv.split('=')[1]
-for w, rep in [(w, r) for w in workers for r in range(2)]:
-    os.environ['PS_WORKERS_PER_GPU'] = str(w)
-    print('PS_WORKERS_PER_GPU=%d' % w, flush=True)
-    t = time.time(); os.environ['PS_VERBOSE']='1'; capi.ps_map(16, '-1', '/tmp/e2e.errorprofile', '/tmp/e2e.indelprofile', fa, fq, '/tmp/e2e.sam'); dt = time.time() - t
+# further arguments: one run pair per argument, each a comma-joined list of NAME=value settings for the library (after the plain runs)
+configs = [dict(PS_WORKERS_PER_GPU=str(w)) for w in workers] + [dict(kv.split('=') for kv in a.split(',')) for a in sys.argv[5:]]
+for cfg, rep in [(c, r) for c in configs for r in range(2)]:
+    os.environ.update(cfg)
+    print(' '.join('%s=%s' % kv for kv in cfg.items()), flush=True)
+    t = time.time(); os.environ['PS_VERBOSE']='2'; capi.ps_map(16, '-1', '/tmp/e2e.errorprofile', '/tmp/e2e.indelprofile', fa, fq, '/tmp/e2e.sam'); dt = time.time() - t
     print('ps_map (index load + %d reads + SAM written) %.2fs = %.2f M reads/s, SAM %.0f MB' % (n, dt, n / dt / 1e6, os.path.getsize('/tmp/e2e.sam') / 1e6), flush=True)
+    if rep == 1:
+        for k in cfg: os.environ.pop(k, None)
 for lvl in (() if len(sys.argv) > 4 and sys.argv[4] == 'nobam' else ('6', '1')):            # the fused route: FASTQ -> filtered BAM, no SAM text
     os.environ['PS_BAM_LEVEL'] = lvl
     for kw in (dict(min_mapq=10), dict(min_mapq=10, sort_by_coordinate=True, write_index=True)):
