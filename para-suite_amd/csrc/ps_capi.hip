@@ -10,6 +10,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <fcntl.h>
+#include <unistd.h>
 #include "../../include/parasuite_hip.h"
 #include "ps_pipeline.h"
 #include "ps_bam.h"
@@ -27,12 +29,23 @@ struct ps_batch { std::unique_ptr<Batch> b; };
 
 static_assert(sizeof(ps_aln) == sizeof(AlnRec), "ps_aln layout");
 
+// Written pieces of ps_map are freed by threads of their own (gigabytes of host memory per piece: 0.18 s for 7.7 M reads), and the call
+// does not wait for the last of them: they are joined by the next call, by ps_release_host_cache and when the process exits.
+namespace {
+struct Trash {
+    std::mutex mu; std::vector<std::thread> th; bool hooked = false;
+    void add(std::thread &&t) { std::lock_guard<std::mutex> l(mu); th.push_back(std::move(t)); if (!hooked) { hooked = true; std::atexit([]() { trash().collect(); }); } }
+    void collect() { std::vector<std::thread> all; { std::lock_guard<std::mutex> l(mu); all.swap(th); } for (auto &t : all) if (t.joinable()) t.join(); }
+    static Trash &trash() { static Trash *t = new Trash(); return *t; }       // never destroyed: a thread may still run at exit
+};
+}
 // bounded hand-over between the stages of ps_map
 namespace {
 template <class T> struct Chan {
-    std::mutex m; std::condition_variable cv; std::deque<T> q; bool closed = false; size_t cap = 2;
+    std::mutex m; std::condition_variable cv; std::deque<T> q; bool closed = false; size_t cap = 2; int waiting = 0;
     void push(T &&v) { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return q.size() < cap || closed; }); if (closed) return; q.push_back(std::move(v)); cv.notify_all(); }
-    bool pop(T &v) { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return !q.empty() || closed; }); if (q.empty()) return false; v = std::move(q.front()); q.pop_front(); cv.notify_all(); return true; }
+    bool pop(T &v) { std::unique_lock<std::mutex> l(m); ++waiting; cv.wait(l, [&] { return !q.empty() || closed; }); --waiting; if (q.empty()) return false; v = std::move(q.front()); q.pop_front(); cv.notify_all(); return true; }
+    bool hungry() { std::lock_guard<std::mutex> l(m); return q.empty() && waiting > 0; }     // somebody waits for work and there is none
     void close() { std::lock_guard<std::mutex> l(m); closed = true; cv.notify_all(); }      // what is queued is still handed out
     void abort() { std::lock_guard<std::mutex> l(m); closed = true; q.clear(); cv.notify_all(); }
 };
@@ -405,21 +418,26 @@ static int map_core(int threads, const char *mm, const char *error_profile, cons
         const int G = (int)devs.size();
         int n_workers = 0; for (int w : dev_workers) n_workers += w;
         // ---- piece size from the input
-        // few, large pieces: every search launch ends with its longest read (a 0.44 M-read piece took 243 ms, 10 M reads in one launch
-        // 1.4 s), so six growing pieces cost 2.5 s of search where three cost 1.8 s
-        size_t chunk_bytes = (size_t)400 << 20, first_bytes = 0;
-        if (const char *e = std::getenv("PS_CHUNK_MB")) { chunk_bytes = (size_t)std::max(1, std::atoi(e)) << 20; first_bytes = 0; }   // stated: taken as it is
+        // Few, large pieces: every search launch ends with its longest read (~0.25 s of a launch are that, whatever its size: a 1.25 M-read
+        // launch takes 0.37 s, 10 M reads in one 1.1 s).  The parser hands over what it has when a worker WAITS for work (the first piece
+        // as soon as the index is resident) but not less than 30 % of the input, and otherwise lets a piece grow to 1 GB; with several
+        // workers a piece is at most 1/(2 x workers) of the input, so that all of them get some.
+        size_t chunk_bytes = (size_t)1 << 30, first_bytes = 0, hungry_min = (size_t)128 << 20;
+        if (const char *e = std::getenv("PS_CHUNK_MB")) { chunk_bytes = (size_t)std::max(1, std::atoi(e)) << 20; hungry_min = chunk_bytes; }   // stated: taken as it is
         else {
             FILE *f = std::fopen(fastq, "rb");
             if (f) {
                 if (fseeko(f, 0, SEEK_END) == 0) {
                     const off_t sz = ftello(f);
-                    if (sz > 0) chunk_bytes = std::min(chunk_bytes, std::max<size_t>((size_t)16 << 20, ((size_t)sz + 2 * (size_t)n_workers - 1) / (2 * (size_t)n_workers) + ((size_t)64 << 10)));   // + slack: cuts fall behind whole records, the last piece must not be a few reads
+                    if (sz > 0) {
+                        if (n_workers > 1) chunk_bytes = std::min(chunk_bytes, std::max<size_t>((size_t)16 << 20, ((size_t)sz + 2 * (size_t)n_workers - 1) / (2 * (size_t)n_workers) + ((size_t)64 << 10)));   // + slack: cuts fall behind whole records, the last piece must not be a few reads
+                        hungry_min = std::min(chunk_bytes, std::max(hungry_min, (size_t)sz * 3 / 10));
+                    }
                 }
                 std::fclose(f);
             }
         }
-
+        if (const char *e = std::getenv("PS_HUNGRY_MIN_MB")) hungry_min = (size_t)std::max(1, std::atoi(e)) << 20;
         if (const char *e = std::getenv("PS_FIRST_MB")) first_bytes = (size_t)std::max(1, std::atoi(e)) << 20;      // first piece (the following ones double up to the piece size)
         struct Piece { int64_t seq = 0; std::unique_ptr<Batch> b; };
         Chan<Piece> parsed;
@@ -444,17 +462,18 @@ static int map_core(int threads, const char *mm, const char *error_profile, cons
         auto fail_all = [&](const std::string &m) { { std::lock_guard<std::mutex> l(mu); if (!failed) { failed = true; msg = m; } } cv.notify_all(); parsed.abort(); };
         double t_parse = 0, t_write = 0, t_release = 0, t_index = 0, t_index_all = 0, t_profile = 0; std::vector<double> t_gpu((size_t)n_workers, 0.0);
         int64_t n_reads = 0, n_pieces = 0;
-        std::vector<std::thread> trash;                  // threads that free written pieces; joined at the end
+        Trash::trash().collect();                        // what an earlier call left to be freed
         // ---- parser (starts at once)
         std::thread parser([&]() {
             try {
                 int64_t seq = 0;
                 int pthr = nthr;                                       // all of them: the GPU waits for the first piece, and sharing the cores with the writer later cost nothing measurable (2.78-2.90 -> 2.67-2.80 s per 10 M reads against half of them)
                 if (const char *e = std::getenv("PS_PARSE_THREADS")) pthr = std::max(1, std::atoi(e));
+                const std::function<bool()> hungry = [&]() { return parsed.hungry(); };
                 load_reads_chunked(fastq, pthr, chunk_bytes, [&](ReadSet &&rs) {
                     Piece p; p.seq = seq++; p.b = batch_prepare(&xs[0]->c, std::move(rs), pthr);     // host only
                     parsed.push(std::move(p));
-                }, first_bytes);
+                }, first_bytes, &hungry, hungry_min);
                 t_parse = since();
             } catch (const std::exception &e) { fail_all(e.what()); }
             parsed.close();
@@ -463,6 +482,8 @@ static int map_core(int threads, const char *mm, const char *error_profile, cons
         std::thread writer([&]() {
             try {
                 bool first = true;
+                SamScratch scratch;
+                if (!bam) { const int fd = ::open(out_sam, O_WRONLY | O_CREAT | O_TRUNC, 0644); if (fd >= 0) ::close(fd); }    // an output file that exists is emptied now, while this thread has nothing to do: giving back 2 GB of cached pages takes 0.3 s
                 std::unique_ptr<BamSink> bsink;                        // ps_map_to_bam: records go out as BAM, no SAM text at all
                 std::unique_ptr<ProfileAccum> accum;                   // on the first device, whose index is resident before any piece is finished
                 for (;;) {
@@ -485,7 +506,7 @@ static int map_core(int threads, const char *mm, const char *error_profile, cons
                         std::vector<std::string> enc; std::vector<std::vector<BamRec>> recs;
                         batch_bam_records(*b, bam->min_mapq, nthr, enc, recs);
                         bsink->add(enc, recs, (uint64_t)b->rs.n);
-                    } else batch_write_sam(*b, out_sam, first, PS_PG_LINE, nthr, !first);
+                    } else batch_write_sam(*b, out_sam, first, PS_PG_LINE, nthr, !first, &scratch);
                     t_write += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
                     if (sink) {                                        // the same records, straight from memory, into the profile histograms
                         const auto tp = std::chrono::steady_clock::now();
@@ -499,7 +520,7 @@ static int map_core(int threads, const char *mm, const char *error_profile, cons
                     { std::lock_guard<std::mutex> l(mu); ++write_next; }
                     cv.notify_all();
                     const auto t1 = std::chrono::steady_clock::now();
-                    { Batch *q = b.release(); std::lock_guard<std::mutex> l(mu); trash.emplace_back([q]() { delete q; }); }   // pinned record buffers, the reads (~40 ms per piece): released on a thread of its own, neither on the GPU worker's time nor on the writer's
+                    { Batch *q = b.release(); Trash::trash().add(std::thread([q]() { delete q; })); }   // pinned record buffers, the reads (~40 ms per piece): released on a thread of its own, neither on the GPU worker's time nor on the writer's
                     t_release += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
                 }
                 if (first) {                      // no reads at all: the header alone, as upstream's samse prints it before its read loop
@@ -614,7 +635,6 @@ static int map_core(int threads, const char *mm, const char *error_profile, cons
         if (early_release.joinable()) early_release.join();
         done.clear();
         close_all();
-        for (auto &t : trash) t.join();
         const double t_closed = since();
         if (failed) return fail(msg);
         if (verbose) {
@@ -661,7 +681,7 @@ int ps_map_to_bam(int threads, const char *mm, const char *error_profile, const 
 }
 
 // page-locked host buffers the library keeps between calls (ps_pipeline.h, PinBuf): given back to the system
-void ps_release_host_cache(void) { try { pin_cache_release(); } catch (...) {} }
+void ps_release_host_cache(void) { try { Trash::trash().collect(); pin_cache_release(); } catch (...) {} }
 
 // host-only: parse reads the way ps_map does (whole file on `threads` threads, or streamed in windows of chunk_bytes) and
 // summarise what came out -- {reads, bases, order-sensitive hash of names/sequences/qualities, pieces}

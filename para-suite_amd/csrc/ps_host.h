@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -41,7 +42,11 @@ struct Contig { std::string name, anno; int64_t offset; int32_t len; int32_t n_a
 struct Hole { int64_t offset; int32_t len; char amb; };
 struct RefSeq {
     std::vector<Contig> contigs; std::vector<Hole> holes;
-    std::vector<uint8_t> pac;   // forward strand, 2 bit
+    std::vector<uint8_t> pac;   // forward strand, 2 bit (index build, ps_ctx_from_blobs)
+    // index_load maps the .pac FILE instead (read-only, shared with the page cache): a copy of hg19's 775 MB took 0.1 s to make and
+    // 0.1 s to give back at the end of every ps_map call
+    std::shared_ptr<const void> pac_map; const uint8_t *pac_view = nullptr;
+    const uint8_t *pac_data() const { return pac_view ? pac_view : pac.data(); }
     int64_t l_pac = 0;
     int pos2rid(int64_t pos_f) const;
     int cnt_ambi(int64_t pos_f, int len, int *ref_id) const;

@@ -20,6 +20,7 @@
 #include <mutex>
 #include <fcntl.h>
 #include <unistd.h>
+#include <sys/mman.h>
 #include "ps_host.h"
 #include "ps_core.h"
 
@@ -691,6 +692,26 @@ void index_save(const Index &ix, const std::string &prefix)
     if (!a.good()) throw Error("cannot write " + prefix + ".ann");
 }
 
+// the .pac file mapped for the host side; if it cannot be mapped, read into ref.pac
+static void map_pac(const std::string &path, size_t n_bytes, RefSeq &ref)
+{
+    ref.pac_map.reset(); ref.pac_view = nullptr;
+    const int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) throw Error("cannot open " + path);
+    struct Closer { int fd; ~Closer() { ::close(fd); } } closer{fd};
+    const size_t total = 16 + n_bytes;
+    void *m = ::mmap(nullptr, total, PROT_READ, MAP_SHARED, fd, 0);
+    if (m != MAP_FAILED) {
+        ref.pac_map = std::shared_ptr<const void>(m, [total](const void *q) { ::munmap(const_cast<void *>(q), total); });
+        ref.pac_view = static_cast<const uint8_t *>(m) + 16;
+        ref.pac.clear(); ref.pac.shrink_to_fit();
+        return;
+    }
+    ref.pac.resize(n_bytes);
+    size_t have = 0;
+    while (have < n_bytes) { const ssize_t r = ::pread(fd, ref.pac.data() + have, n_bytes - have, (off_t)(16 + have)); if (r <= 0) throw Error("truncated " + path); have += (size_t)r; }
+}
+
 void index_load(const std::string &prefix, Index &ix, hipStream_t s)
 {
     std::ifstream a(prefix + ".ann", std::ios::binary);
@@ -700,7 +721,8 @@ void index_load(const std::string &prefix, Index &ix, hipStream_t s)
     LoadStage st;
     read_dev(st, prefix + ".bwt", MAGIC_BWT, ix.blocks, s);
     read_dev(st, prefix + ".sa", "PSSA0002", ix.sa, s);
-    read_dev(st, prefix + ".pac", "PSPAC001", ix.pac, s, &ix.ref.pac);    // the host keeps the pac too (MD tags)
+    read_dev(st, prefix + ".pac", "PSPAC001", ix.pac, s, nullptr);
+    map_pac(prefix + ".pac", ix.pac.n, ix.ref);                             // the host reads the pac too (MD tags)
     bwtint primary = ix.view.primary; bwtint L2[5]; std::memcpy(L2, ix.view.L2, sizeof L2);
     ix.refresh_view();
     ix.view.primary = primary; std::memcpy(ix.view.L2, L2, sizeof L2);

@@ -9,17 +9,31 @@
 
 namespace ps {
 
+// std::vector without the zero fill of resize(): the parser's arrays (hundreds of MB per piece) are written once, by many threads
+template <class T> struct DefaultInit : std::allocator<T> {
+    template <class U> struct rebind { using other = DefaultInit<U>; };
+    DefaultInit() noexcept {}
+    template <class U> DefaultInit(const DefaultInit<U> &) noexcept {}
+    template <class U> void construct(U *p) noexcept(std::is_nothrow_default_constructible<U>::value) { ::new (static_cast<void *>(p)) U; }
+    template <class U, class... A> void construct(U *p, A &&...a) { ::new (static_cast<void *>(p)) U(std::forward<A>(a)...); }
+};
+template <class T> using RawVec = std::vector<T, DefaultInit<T>>;
+
 struct ReadSet {
     int64_t n = 0;
-    std::vector<int32_t> len;
-    std::vector<int64_t> off;        // n+1 offsets into seq / qual
-    std::vector<uint8_t> seq;        // codes 0..3, 4 = N, read orientation
-    std::vector<char> qual; bool has_qual = false;
-    std::vector<char> names; std::vector<int64_t> name_off;  // n+1
+    RawVec<int32_t> len;
+    RawVec<int64_t> off;             // n+1 offsets into seq / qual
+    RawVec<uint8_t> seq;             // codes 0..3, 4 = N, read orientation
+    RawVec<char> qual; bool has_qual = false;
+    RawVec<char> names; RawVec<int64_t> name_off;            // n+1
     const char *name(int64_t i, size_t &l) const { l = (size_t)(name_off[i + 1] - name_off[i]); return names.data() + name_off[i]; }
 };
 void load_reads(const char *path, ReadSet &rs, int threads = 1); // FASTQ or FASTA
-void load_reads_chunked(const char *path, int threads, size_t chunk_bytes, const std::function<void(ReadSet &&)> &sink, size_t first_bytes = 0);
+// The input in pieces of whole records, in order; sink(piece) may block.  The file is STREAMED in windows of <= 64 MB; a piece is the
+// windows parsed so far and goes out when another window would take it over chunk_bytes (first_bytes for the first piece, doubling from
+// there) or -- `hungry` given -- as soon as it holds hungry_min_bytes and hungry() says that the stage behind is waiting for work.
+void load_reads_chunked(const char *path, int threads, size_t chunk_bytes, const std::function<void(ReadSet &&)> &sink, size_t first_bytes = 0,
+                        const std::function<bool()> *hungry = nullptr, size_t hungry_min_bytes = 0);
 void reads_from_codes(int64_t n, int len, const uint8_t *codes, ReadSet &rs);
 
 static const int PS_HIT_CIGAR = 8;
@@ -156,7 +170,10 @@ void reserve_search_workspace(Ctx *ctx, int work_index);        // the big devic
 void batch_locate(Batch &b);                                    // SA walk kernel, strand / MAPQ, banded DP of gapped hits
 void batch_bam_records(const Batch &b, int min_mapq, int threads, std::vector<std::string> &enc, std::vector<std::vector<BamRec>> &recs);   // the located batch as BAM records (MAPQ >= min_mapq): one buffer per thread, buffers in input order
 std::string sam_header(const RefSeq &ref, const char *pg_line);      // @SQ lines in FASTA order + the @PG line
-void batch_write_sam(Batch &b, const char *path, bool header, const char *pg_line, int threads, bool append = false);
+// text buffers of the SAM writer, kept from piece to piece by ps_map: fresh ones are first touched page by page, and a page fault waits
+// while another thread gives a finished piece's gigabytes back to the system (0.2 s per piece, measured)
+struct SamScratch { std::vector<std::string> bufs[2]; };
+void batch_write_sam(Batch &b, const char *path, bool header, const char *pg_line, int threads, bool append = false, SamScratch *scratch = nullptr);
 // the located hits with MAPQ >= min_mapq as records for the error-profile kernel (what the MAPQ-filtered BAM of the first pass holds:
 // PARAsuiteMapping.java:124-133 -> ErrorProfiling.java:145-172), appended to `out`; host memory only
 void batch_profile_records(const Batch &b, int min_mapq, int threads, ProfRecords &out);
