@@ -84,8 +84,7 @@ __global__ void __launch_bounds__(256) k_effort(EffortArgs a)
 {
     const int stride = gridDim.x * blockDim.x;
     LaneStats st = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < a.n_reads; t += stride) {
-        const int r = a.order ? a.order[t] : t;
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < a.n_reads; r += stride) {
         const int len = a.lens ? a.lens[r] : a.len, half = len >> 1;
         EChain A = {0, a.ix.seq_len, 0, 0, 0, 0, 0, 0, 0, 0}, B = A;
         uint32_t bwA = 0, mwA = 0, bwB = 0, mwB = 0;
@@ -124,8 +123,7 @@ __global__ void __launch_bounds__(256) k_effort_model(EffortModelArgs a)
     const int NU = a.max_units + 2;
     float *Wa = smem_f + (size_t)threadIdx.x * 2 * NU, *Wb = Wa + NU;
     const int stride = gridDim.x * blockDim.x;
-    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < a.n_reads; t += stride) {
-        const int r = a.order ? a.order[t] : t;
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < a.n_reads; r += stride) {
         const int len = a.lens ? a.lens[r] : a.len;
         const int own = (a.lens && a.units_by_len) ? (int)a.units_by_len[len] : a.max_units;
         int B = (int)a.est[r] + a.u_tight;
@@ -180,7 +178,7 @@ __global__ void __launch_bounds__(256) k_effort_model(EffortModelArgs a)
         tot += left * (float)(len - depth);                               // what is still alive walks the rest of the read
         const float lg = __log2f(tot + 1.f) * (float)a.log_scale;
         int q = (int)lg; if (q > 255) q = 255; if (q < 0) q = 0;
-        a.key[t] = (uint8_t)(255 - q);                                    // ascending sort = heaviest first
+        a.key[r] = (uint8_t)(255 - q);                                    // ascending sort = heaviest first
         if (a.pred) a.pred[r] = tot;
     }
 }

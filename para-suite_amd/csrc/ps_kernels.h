@@ -14,7 +14,6 @@ struct WidthArgs {
     const uint32_t *bases; const uint32_t *nmask;
     uint32_t *w; uint32_t *cwb; uint32_t *cswb;   // compact width bytes, 4 positions per word, [word][n_reads]
     KStats *stats;
-    const int32_t *order;    // optional: thread t works on read order[t] (reads that begin alike side by side: their Occ loads coalesce)
 };
 
 // Effort estimate (scheduling only, never a result): a read's search effort follows the score of its best hit, which is unknown
@@ -28,7 +27,6 @@ struct EffortArgs {
     int c_restart;           // charged where a scan has to start a new piece
     uint32_t w_pin;          // a substitution is believed where the interval is at most this wide (the scan has pinned its locus down)
     uint8_t *est;            // out: estimated score of the best hit, clipped to 255
-    const int32_t *order;    // optional, as WidthArgs::order
     uint16_t *est_ab;        // optional (profiling): the two scans' totals (7 bits each) and whether each had to start over (bit 7)
 };
 
@@ -44,8 +42,7 @@ struct EffortModelArgs {
     int depth;               // levels modelled (beyond ~19 symbols a random string no longer occurs in a genome of this size)
     float rows;              // BWT rows: a string of d symbols has min(1, rows / 4^d) expected occurrences
     int log_scale;           // key = 255 - log2(expected nodes) * log_scale
-    uint8_t *key; float *pred;      // pred: optional (profiling).  key[t] belongs to read order[t]: the keys lie in the sequence the order gives
-    const int32_t *order;    // optional, as WidthArgs::order
+    uint8_t *key; float *pred;      // pred: optional (profiling)
 };
 
 struct RefineItem { int32_t read; bwtint rb; int32_t ref_shift; int32_t strand; };

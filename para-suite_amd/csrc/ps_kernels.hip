@@ -42,8 +42,7 @@ __global__ void __launch_bounds__(256) k_width(WidthArgs a)
 {
     const int stride = gridDim.x * blockDim.x;
     LaneStats st = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < a.n_reads; t += stride) {
-        const int r = a.order ? a.order[t] : t;
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < a.n_reads; r += stride) {
         WChain A, B;
         wchain_init(a.ix, A); wchain_init(a.ix, B);
         const int len = a.lens ? a.lens[r] : a.len, seed_len = a.seed_len;

@@ -431,6 +431,25 @@ void reads_from_codes(int64_t n, int len, const uint8_t *codes, ReadSet &rs)
     rs.has_qual = false;
 }
 
+// host loops over millions of reads: contiguous ranges on a few threads; f(begin, end, thread)
+template <class F> static void par_for(size_t n, int threads, F f)
+{
+    size_t nt = (size_t)std::max(1, threads);
+    if (nt > n / 8192 + 1) nt = n / 8192 + 1;
+    if (nt <= 1) { if (n) f((size_t)0, n, 0); return; }
+    std::vector<std::thread> th;
+    std::vector<std::exception_ptr> err(nt);
+    const size_t per = (n + nt - 1) / nt;
+    for (size_t t = 0; t < nt; ++t)
+        th.emplace_back([&, t]() {
+            const size_t a0 = t * per, b0 = std::min(n, a0 + per);
+            try { if (a0 < b0) f(a0, b0, (int)t); } catch (...) { err[t] = std::current_exception(); }
+        });
+    for (auto &x : th) x.join();
+    for (auto &e : err) if (e) std::rethrow_exception(e);
+}
+static int par_threads(size_t n, int threads) { size_t nt = (size_t)std::max(1, threads); if (nt > n / 8192 + 1) nt = n / 8192 + 1; return (int)std::max<size_t>(1, nt); }
+
 // ------------------------------------------------------------ batch set-up ---
 // host half of batch_create: bins, order inside the bins, 2-bit packing -- no device call, so the parser thread of
 // ps_map runs it while the GPU thread is busy with the piece before
@@ -466,12 +485,42 @@ std::unique_ptr<Batch> batch_prepare(Ctx *ctx, ReadSet &&rs_in, int threads)
         b->read_bin[g] = cls; b->read_local[g] = (int32_t)bin.ids.size();
         bin.ids.push_back((int32_t)g);
     }
-    // The reads of a bin stay in input order.  (Until round 3 they were sorted here by their leading bases, for the search kernel's
-    // sake: a radix sort on one thread, 0.15 s per 3.6 M reads of the parser's time.  The device now makes that order itself, as a
-    // list the kernels read: run_search.)
     for (Bin &bin : b->bins) {
         std::string err;
         if (!make_model(ctx->opt, bin.len, bin.md, err)) throw Error(err);
+        // Order the reads of a bin by their leading bases (the search consumes a read from its first base): the
+        // lanes of a wave then walk the same top levels of the BWT, so their Occ loads coalesce and hit in cache.
+        // Results return to input order through ids[]; the order inside a bin is free.  (Handing the kernels a sorted
+        // LIST instead and leaving the reads where they are cost the search kernel 1.6 % and the width stage 20 %:
+        // profiles/r03_kernel_experiments.txt.)  An LSD radix sort over the first 16 bases, every pass on all threads:
+        // counts per thread and digit, places from their prefix sums (stable), 0.15 s per 3.6 M reads when one thread did it.
+        if (!std::getenv("PS_KEEP_ORDER")) {         // PS_KEEP_ORDER=1: the reads stay in input order (tools/order_probe.py hands them out in an order of its own)
+            const size_t n = bin.ids.size();
+            const int nt = par_threads(n, threads);
+            std::vector<uint32_t> key(n), key2(n); std::vector<int32_t> id2(n);
+            par_for(n, nt, [&](size_t r0, size_t r1, int) {
+                for (size_t r = r0; r < r1; ++r) {
+                    const uint8_t *sq = rs.seq.data() + rs.off[bin.ids[r]];
+                    const int kb = rs.len[bin.ids[r]] < 16 ? rs.len[bin.ids[r]] : 16;
+                    uint32_t k = 0;
+                    for (int j = 0; j < kb; ++j) k = (k << 2) | (uint32_t)(sq[j] & 3);
+                    key[r] = k << (2 * (16 - kb));
+                }
+            });
+            std::vector<size_t> cnt((size_t)nt * 256);
+            for (int sh = 0; sh < 32; sh += 8) {
+                std::fill(cnt.begin(), cnt.end(), 0);
+                par_for(n, nt, [&](size_t r0, size_t r1, int t) { size_t *c = cnt.data() + (size_t)t * 256; for (size_t r = r0; r < r1; ++r) ++c[(key[r] >> sh) & 0xff]; });
+                size_t at = 0;
+                for (int d = 0; d < 256; ++d) for (int t = 0; t < nt; ++t) { const size_t c = cnt[(size_t)t * 256 + d]; cnt[(size_t)t * 256 + d] = at; at += c; }
+                par_for(n, nt, [&](size_t r0, size_t r1, int t) {
+                    size_t *c = cnt.data() + (size_t)t * 256;
+                    for (size_t r = r0; r < r1; ++r) { const size_t p = c[(key[r] >> sh) & 0xff]++; key2[p] = key[r]; id2[p] = bin.ids[r]; }
+                });
+                key.swap(key2); bin.ids.swap(id2);
+            }
+            par_for(n, nt, [&](size_t r0, size_t r1, int) { for (size_t r = r0; r < r1; ++r) b->read_local[bin.ids[r]] = (int32_t)r; });
+        }
         const size_t n = bin.ids.size();
         bin.n_bw = (bin.len + 15) / 16; bin.n_mw = (bin.len + 31) / 32;
         bin.h_bases.assign((size_t)bin.n_bw * n, 0); bin.h_nmask.assign((size_t)bin.n_mw * n, 0);
@@ -536,22 +585,11 @@ __global__ void k_clip_counts(const int32_t *n_aln, int aln_cap, int n, uint32_t
 }
 
 // hand-out order of a search launch: queue position -> read, heaviest estimated search first, the given (leading-base) order inside a class
-__global__ void k_order_keys(const uint8_t *est, const int32_t *lead, int n, int cap, uint8_t *key)
-{
-    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
-        const int r = lead ? lead[t] : t;
-        const int e = est[r] > cap ? cap : est[r];
-        key[t] = (uint8_t)(cap - e);
-    }
-}
-// the first 16 bases of every read as a key, first base in the top bits (word 0 of the packed read holds base j at bits 2j, 2j+1;
-// positions behind the read's end and N are 0 there)
-__global__ void k_lead_keys(const uint32_t *bases, int n, uint32_t *key, int32_t *iota)
+__global__ void k_order_keys(const uint8_t *est, int n, int cap, uint8_t *key, int32_t *iota)
 {
     for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
-        const uint32_t x = __brev(bases[r]);                               // base j now at bits 31-2j (low bit of the pair) and 30-2j (high bit)
-        key[r] = ((x & 0xAAAAAAAAu) >> 1) | ((x & 0x55555555u) << 1);
-        iota[r] = r;
+        const int e = est[r] > cap ? cap : est[r];
+        key[r] = (uint8_t)(cap - e); iota[r] = r;
     }
 }
 
@@ -567,25 +605,6 @@ struct EvTimer {
 };
 
 
-// host loops over millions of reads: contiguous ranges on a few threads; f(begin, end, thread)
-template <class F> static void par_for(size_t n, int threads, F f)
-{
-    size_t nt = (size_t)std::max(1, threads);
-    if (nt > n / 8192 + 1) nt = n / 8192 + 1;
-    if (nt <= 1) { if (n) f((size_t)0, n, 0); return; }
-    std::vector<std::thread> th;
-    std::vector<std::exception_ptr> err(nt);
-    const size_t per = (n + nt - 1) / nt;
-    for (size_t t = 0; t < nt; ++t)
-        th.emplace_back([&, t]() {
-            const size_t a0 = t * per, b0 = std::min(n, a0 + per);
-            try { if (a0 < b0) f(a0, b0, (int)t); } catch (...) { err[t] = std::current_exception(); }
-        });
-    for (auto &x : th) x.join();
-    for (auto &e : err) if (e) std::rethrow_exception(e);
-}
-static int par_threads(size_t n, int threads) { size_t nt = (size_t)std::max(1, threads); if (nt > n / 8192 + 1) nt = n / 8192 + 1; return (int)std::max<size_t>(1, nt); }
-
 // width + backtracking kernels over n reads of one length that are already packed on the device
 static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases, const uint32_t *d_nmask, const int32_t *d_lens,
                        uint32_t pool_cap, int aln_cap, AlnRec *alns, int32_t *n_aln, uint8_t *status)
@@ -598,43 +617,21 @@ static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases
     WidthArgs wa;
     wa.ix = ctx->ix.view; wa.n_reads = n; wa.len = len; wa.lens = d_lens; wa.seed_len = seed_len; wa.use_seed = md.use_seed;
     wa.bases = d_bases; wa.nmask = d_nmask; wa.w = w; wa.cwb = cwb; wa.cswb = cswb; wa.stats = b.d_stats.p + 0;
-    int min_n = 4096;                                         // below that every read has a lane to itself at once: no order to choose
-    if (const char *e = std::getenv("PS_ORDER_MIN")) min_n = std::max(1, std::atoi(e));      // tests: the small launches of the fuzz sweep too
-    // ---- the reads by their leading bases (the search consumes a read from its first base): the lanes of a wave then walk the same
-    // top levels of the BWT, so their Occ loads coalesce and hit in cache.  The reads stay where they are (input order inside the bin);
-    // the order is a list the kernels read.  (The host sorted them until round 3: 0.15 s per 3.6 M reads on the parser's one thread.)
-    // PS_KEEP_ORDER=1: input order (tools/order_probe.py hands the reads out in an order of its own).
-    const int32_t *d_lead = nullptr;
-    double ms_order = 0;
-    if (n >= min_n && !std::getenv("PS_KEEP_ORDER")) {
-        EvTimer t(s);
-        uint32_t *lk = wk->ws_get<uint32_t>("lead_key", (size_t)n), *lk2 = wk->ws_get<uint32_t>("lead_key2", (size_t)n);
-        int32_t *li = wk->ws_get<int32_t>("lead_iota", (size_t)n), *lead = wk->ws_get<int32_t>("lead_order", (size_t)n);
-        hipLaunchKernelGGL(k_lead_keys, dim3(std::min((n + 255) / 256, 4096)), dim3(256), 0, s, d_bases, n, lk, li);
-        size_t tb = 0;
-        PS_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, lk, lk2, li, lead, n, 0, 32, s));
-        uint8_t *tmp = wk->ws_get<uint8_t>("order_tmp", tb ? tb : 1);
-        PS_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tb, lk, lk2, li, lead, n, 0, 32, s));
-        PS_HIP(hipGetLastError());
-        ms_order = t.stop();
-        d_lead = lead;
-    }
-    wa.order = d_lead;
-    { EvTimer t(s); launch_width(wa, s); PS_HIP(hipGetLastError()); b.tm.ms_width += t.stop() + ms_order; ++b.tm.n_width_launches; }
+    { EvTimer t(s); launch_width(wa, s); PS_HIP(hipGetLastError()); b.tm.ms_width += t.stop(); ++b.tm.n_width_launches; }
     // ---- hand-out order: the reads with the heaviest predicted search first (ps_effort.hip), so that the launch does not end on
-    // them; reads of one class keep the leading-base order.  PS_ORDER=0 switches it off, 2 orders by the estimated best score alone (A/B runs).
-    const int32_t *d_order = d_lead; const uint8_t *d_est = nullptr; const uint16_t *d_est_ab = nullptr;
+    // them.  PS_ORDER=0 switches it off, 2 orders by the estimated best score alone (A/B runs).
+    const int32_t *d_order = nullptr; const uint8_t *d_est = nullptr; const uint16_t *d_est_ab = nullptr;
     {
         const char *eo = std::getenv("PS_ORDER");
         const int mode = eo ? std::atoi(eo) : 1;
+        int min_n = 4096;                                     // below that every read has a lane to itself at once: no order to choose
+        if (const char *e = std::getenv("PS_ORDER_MIN")) min_n = std::max(1, std::atoi(e));      // tests: the small launches of the fuzz sweep too
         if (mode > 0 && n >= min_n && md.max_units >= md.c_min) {      // a search that can afford no difference is ~len steps for every read: nothing to order
             EvTimer t(s);
             uint8_t *est = wk->ws_get<uint8_t>("est", (size_t)n), *key = wk->ws_get<uint8_t>("okey", (size_t)n), *key2 = wk->ws_get<uint8_t>("okey2", (size_t)n);
-            int32_t *order = wk->ws_get<int32_t>("order", (size_t)n);
-            const int32_t *vals = d_lead;
-            if (!vals) { int32_t *iota = wk->ws_get<int32_t>("oiota", (size_t)n); hipLaunchKernelGGL(k_iota, dim3(std::min((n + 255) / 256, 4096)), dim3(256), 0, s, n, iota); vals = iota; }
+            int32_t *iota = wk->ws_get<int32_t>("oiota", (size_t)n), *order = wk->ws_get<int32_t>("order", (size_t)n);
             EffortArgs ea;
-            ea.ix = ctx->ix.view; ea.n_reads = n; ea.len = len; ea.lens = d_lens; ea.bases = d_bases; ea.nmask = d_nmask; ea.est = est; ea.order = d_lead;
+            ea.ix = ctx->ix.view; ea.n_reads = n; ea.len = len; ea.lens = d_lens; ea.bases = d_bases; ea.nmask = d_nmask; ea.est = est;
             // everything here is in BUDGET UNITS (what the search's limits are in): the profile model has units == score, stock counts
             // every difference as one unit whatever it scores
             int csum = 0;
@@ -653,10 +650,10 @@ static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases
                 int cap = 255;
                 if (const char *e = std::getenv("PS_ORDER_CAP")) cap = std::max(1, std::min(255, std::atoi(e)));
                 bits = 1; while ((1 << bits) <= cap) ++bits;
-                hipLaunchKernelGGL(k_order_keys, dim3(std::min((n + 255) / 256, 4096)), dim3(256), 0, s, est, d_lead, n, cap, key);
+                hipLaunchKernelGGL(k_order_keys, dim3(std::min((n + 255) / 256, 4096)), dim3(256), 0, s, est, n, cap, key, iota);
             } else {
                 EffortModelArgs em;
-                em.n_reads = n; em.len = len; em.lens = d_lens; em.units_by_len = nullptr; em.bases = d_bases; em.nmask = d_nmask; em.cwb = cwb; em.est = est; em.order = d_lead;
+                em.n_reads = n; em.len = len; em.lens = d_lens; em.units_by_len = nullptr; em.bases = d_bases; em.nmask = d_nmask; em.cwb = cwb; em.est = est;
                 for (int c = 0; c < 5; ++c) em.s_pk[c] = md.u_mm_pk[c];
                 em.inv_c_min = (uint32_t)md.inv_c_min; em.max_units = md.max_units; em.u_tight = md.u_tight;
                 em.seed_units = md.max_seed_diff * md.u_tight; em.use_seed = md.use_seed; em.seed_len = md.seed_len;
@@ -672,12 +669,12 @@ static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases
                 }
                 em.key = key; em.pred = nullptr;
                 launch_effort_model(em, s);
+                hipLaunchKernelGGL(k_iota, dim3(std::min((n + 255) / 256, 4096)), dim3(256), 0, s, n, iota);
             }
-            // the keys lie in leading-base order (key[t] is read vals[t]'s): the stable sort keeps that order inside a class
             size_t tb = 0;
-            PS_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, key, key2, vals, order, n, 0, bits, s));
+            PS_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, key, key2, iota, order, n, 0, bits, s));
             uint8_t *tmp = wk->ws_get<uint8_t>("order_tmp", tb ? tb : 1);
-            PS_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tb, key, key2, vals, order, n, 0, bits, s));
+            PS_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tb, key, key2, iota, order, n, 0, bits, s));
             PS_HIP(hipGetLastError());
             b.tm.ms_width += t.stop();                                        // reported with the width stage: both prepare the search
             d_order = order; d_est = est;
