@@ -50,7 +50,7 @@ struct NLane {
     int r;
     uint32_t lim;                 // best_score (0xff: no hit yet) | max_units<<8 | len<<16 | min(best_cnt, 255)<<24
     uint32_t nsb;                 // n_stack | bump<<16 (live entries; first never-used slot)
-    uint32_t n_phantom;
+    uint32_t n_phantom;           // children counted but not stored (low 24 bits) | the read's estimated best score << 24 (255: none; nt_tail)
     uint32_t fh;                  // free slot: the one popped last (0xffff: none)
     uint32_t bm0, bm1;            // non-empty score buckets 0..31 / 32..63 (narrow tiers have at most 64; two words, not one 64-bit value: with <= 32
                                   // buckets -- every default cost model -- the second word is never touched and costs no register moves)
@@ -61,6 +61,8 @@ PS_HD int nl_max_units(const NLane &L) { return (int)((L.lim >> 8) & 0xffu); }
 PS_HD int nl_len(const NLane &L) { return (int)((L.lim >> 16) & 0xffu); }
 PS_HD int nl_n_stack(const NLane &L) { return (int)(L.nsb & 0xffffu); }
 PS_HD uint32_t nl_bump(const NLane &L) { return L.nsb >> 16; }
+PS_HD uint32_t nl_phantom(const NLane &L) { return L.n_phantom & 0x00FFFFFFu; }
+PS_HD int nl_est(const NLane &L) { return (int)(L.n_phantom >> 24); }
 
 PS_HD void nl_init(NLane &L)
 {
@@ -196,6 +198,17 @@ PS_HD void nt_heads_init(BtMem &m, int n_buckets)
     uint32_t *hw = reinterpret_cast<uint32_t *>(m.heads16);
     for (int p = 0; p < (n_buckets + 1) >> 1; ++p) hw[p] = 0xFFFFFFFFu;
 }
+// The estimate of a read's best score (nt_tail) has failed -- the first hit is worse, or the stack ran empty without a hit: the
+// search starts over from the root without one.  The read is still in the lane's local memory (no hit has been recorded, so
+// nothing has touched its bounds), the budget is still the read's own; only the search state is reset, on the stack the lane holds.
+PS_COLD void nt_restart_without_estimate(const BtArgs &a, NLane &L, BtMem &m)
+{
+    L.ctl = (L.ctl & NL_BIG) | (uint32_t)M_POP | NL_HAVE_CUR;       // status RS_OK, no hit
+    L.kr = 0; L.lr = (uint32_t)a.ix.seq_len; L.wa = (uint32_t)nl_len(L); L.wb = NW_ROOT_C << 6;
+    L.lim = (L.lim & 0x00FFFF00u) | 0xffu;                          // no best score, none counted; budget and length stay
+    L.nsb = 0; L.bm0 = L.bm1 = 0; L.fh = 0xffffu; L.n_phantom = 0xFF000000u;
+    nt_heads_init(m, a.md.n_buckets);
+}
 PS_HD void nt_finish_read(const BtArgs &a, NLane &L)
 {
     a.n_aln[L.r] = nl_n_aln(L.ctl);
@@ -221,6 +234,7 @@ PS_COLD void nt_hit(const BtArgs &a, NLane &L, BtMem &m)
     const int units = md.profile ? score : nw_mm(L.wa) + n_gapo + (md.mode_gape ? nw_gape(L.wa) : 0);
     const int n_aln = nl_n_aln(L.ctl);
     if (n_aln == 0) {
+        if (units > nl_est(L)) { nt_restart_without_estimate(a, L, m); return; }      // the best hit is worse than the estimate children were left out by (nt_tail)
         int t = units + md.u_tight;
         const int own = nl_max_units(L);             // still the read's own budget: nothing has tightened it before the first hit
         t = t > own ? own : t;
@@ -248,7 +262,7 @@ PS_COLD void nt_hit(const BtArgs &a, NLane &L, BtMem &m)
             else if (w == x) {
                 // a bound that drops: children skipped on the strength of it (n_phantom) might have been viable, the
                 // read is redone by the wide tier, which skips nothing (see bt_hit)
-                if (bid > 1 && L.n_phantom) L.ctl = nl_set_status(L.ctl, RS_OVERFLOW_POOL);
+                if (bid > 1 && nl_phantom(L)) L.ctl = nl_set_status(L.ctl, RS_OVERFLOW_POOL);
                 bid = 1; w = shadow - (++j); a.w[off] = w;
             }
             m.cw[i] = cw_pack(bid, i > 0 && w == prev);
@@ -277,6 +291,7 @@ PS_COLD bool nt_fetch(const BtArgs &a, NLane &L, BtMem &m, int q)
     const int len = a.lens ? a.lens[r] : a.len;
     L.r = r;
     L.ctl = (uint32_t)M_FETCH;                           // status RS_OK, no hit, no current entry, on the private stack slice
+    L.n_phantom = 0xFF000000u;                           // nothing counted, no estimate yet (set below, behind the outright rejection)
     // the budget is the read's own (a launch holds reads of every length that shares the seed rule; md is the longest read's)
     const int max_units = (a.lens && a.units_by_len) ? (int)a.units_by_len[len] : md.max_units;
     L.lim = 0xffu | ((uint32_t)max_units << 8) | ((uint32_t)len << 16);
@@ -300,7 +315,11 @@ PS_COLD bool nt_fetch(const BtArgs &a, NLane &L, BtMem &m, int q)
     if (nNu > max_units) { nt_finish_read(a, L); return false; }
     L.kr = 0; L.lr = (uint32_t)a.ix.seq_len; L.wa = (uint32_t)len; L.wb = NW_ROOT_C << 6;     // the root: i = len, state M, score 0
     L.ctl |= NL_HAVE_CUR;
-    L.nsb = 0; L.bm0 = L.bm1 = 0; L.fh = 0xffffu; L.n_phantom = 0;
+    L.nsb = 0; L.bm0 = L.bm1 = 0; L.fh = 0xffffu;
+    {   // the estimate counts only where it is tighter than the read's own budget (else 255: none -- a read without a hit then needs no second search)
+        const int e = a.cap_est ? (int)a.est[r] : 255;
+        L.n_phantom = (uint32_t)(e + md.u_tight < max_units ? e : 255) << 24;
+    }
     nt_heads_init(m, md.n_buckets);
     return true;
 }
@@ -378,11 +397,12 @@ PS_HD int nt_head(const BtArgs &a, const BtHot &h, NLane &L, LaneStats &st, BtMe
     }
     if (mode == M_POP) {
         const int n_virtual = nl_n_stack(L) + ((L.ctl & NL_HAVE_CUR) ? 1 : 0);
-        if (L.n_phantom && (long long)n_virtual + (long long)L.n_phantom > (long long)h.max_entries) {
+        if (nl_phantom(L) && (long long)n_virtual + (long long)nl_phantom(L) > (long long)h.max_entries) {
             // with the skipped children counted the stack-size stop rule might have fired: the exact count is only
             // kept by the wide tier, which stores every child
             L.ctl = nl_set_status(L.ctl, RS_OVERFLOW_POOL); nt_finish_read(a, L); return 0;
         }
+        if (n_virtual == 0 && nl_est(L) != 255 && nl_n_aln(L.ctl) == 0 && nl_status(L.ctl) == RS_OK) { NLane t = L; nt_restart_without_estimate(a, t, m); L = t; return 0; }   // no hit where the estimate promised one
         if (n_virtual == 0 || n_virtual > (int)h.max_entries || nl_status(L.ctl) != RS_OK) { nt_finish_read(a, L); return 0; }
         if (L.ctl & NL_HAVE_CUR) L.ctl &= ~NL_HAVE_CUR;
         else { nt_pop<NB32>(L, m); if (STATS) ++st.pops; }
@@ -482,7 +502,14 @@ PS_HD void nt_tail(const BtHot &h, NLane &L, LaneStats &st, BtMem &m, const NtSt
     // floor((rem - c) / c_min) < bound, i.e. c > rem - bound * c_min.  The budget only ever shrinks, so such a child is dropped
     // whenever it is popped: it is not stored at all, only counted (n_phantom) for the stack-size stop rule.  In profile mode this
     // is about half of all pops.  One threshold per bound, two compares per child.
-    const int thr_same = rem - (int)ps_mul24((uint32_t)bnd_same, h.c_min), thr_del = rem - (int)ps_mul24((uint32_t)bnd_del, h.c_min);
+    //   The estimate of the read's best score (ps_effort.hip; in units, profile costs only) tightens that before the first hit: the
+    // budget will then be at most est + u_tight, and a child whose score is above est is not popped before that hit (lower scores go
+    // first), so it is dropped when popped if it needs more than est + u_tight -- also left out and counted.  If the estimate turns out
+    // too low (first hit worse than est, or no hit) the search of the read starts over without one (nt_restart_without_estimate): results never depend on it.
+    const int need_same = (int)ps_mul24((uint32_t)bnd_same, h.c_min), need_del = (int)ps_mul24((uint32_t)bnd_del, h.c_min);
+    const int cap_rem = nl_est(L) - e_sc, ut = h.u_tight();
+    const int cap_same = cap_rem + (ut > need_same ? ut - need_same : 0), cap_del = cap_rem + (ut > need_del ? ut - need_del : 0);
+    const int thr_same = (rem - need_same) < cap_same ? (rem - need_same) : cap_same, thr_del = (rem - need_del) < cap_del ? (rem - need_del) : cap_del;
     uint32_t phantom = 0, gmask = 0;
     // ---- which children are stored, and their scores (push order: insertion, deletion of A C G T, mismatches) ----
     int sc[9];

@@ -607,7 +607,7 @@ struct EvTimer {
 
 // width + backtracking kernels over n reads of one length that are already packed on the device
 static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases, const uint32_t *d_nmask, const int32_t *d_lens,
-                       uint32_t pool_cap, int aln_cap, AlnRec *alns, int32_t *n_aln, uint8_t *status)
+                       uint32_t pool_cap, int aln_cap, AlnRec *alns, int32_t *n_aln, uint8_t *status, bool first_tier = false)
 {
     Ctx *ctx = b.ctx; Work *wk = b.wk; hipStream_t s = wk->stream;
     const int len = md.len, seed_len = md.seed_len;
@@ -716,6 +716,8 @@ static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases
     a.pool = pool; a.pool_cap = pool_cap; a.heads = heads; a.wide = wide ? 1 : 0; a.stats = b.d_stats.p + 1;
     a.queue = queue; a.fetch_min = ctx->fetch_min; a.hit_min = ctx->hit_min;
     a.order = wide ? nullptr : d_order; a.est = d_est; a.est_ab = d_est_ab;
+    // the estimate also spares the search entries (ps_narrow.h, nt_tail): first tier and profile costs only (units == score); a read it fails on starts over without it inside the launch
+    a.cap_est = (first_tier && !wide && d_est && md.profile && !(std::getenv("PS_CAP") && std::atoi(std::getenv("PS_CAP")) == 0)) ? 1 : 0;
     if (const char *e = std::getenv("PS_FETCH_MIN")) a.fetch_min = std::max(1, std::atoi(e));       // tuning: read at every launch
     if (const char *e = std::getenv("PS_HIT_MIN")) a.hit_min = std::max(1, std::atoi(e));
     if (!wide && pool_cap < 65535 && ctx->n_big > 0) {         // large slots for the reads that outgrow their private slice
@@ -981,7 +983,7 @@ void batch_search(Batch &b)
         bin.host_alns_valid = false;
         if (bin.d_alns.n < (size_t)n * ctx->aln_cap[0]) { bin.d_alns.alloc((size_t)n * ctx->aln_cap[0]); bin.d_n_aln.alloc(n); bin.d_status.alloc(n); }
         bin.aln_cap = ctx->aln_cap[0];
-        run_search(b, bin.md, n, bin.bases.p, bin.nmask.p, bin.ragged ? bin.d_lens.p : nullptr, ctx->pool_cap[0], bin.aln_cap, bin.d_alns.p, bin.d_n_aln.p, bin.d_status.p);
+        run_search(b, bin.md, n, bin.bases.p, bin.nmask.p, bin.ragged ? bin.d_lens.p : nullptr, ctx->pool_cap[0], bin.aln_cap, bin.d_alns.p, bin.d_n_aln.p, bin.d_status.p, true);
         uint8_t *h_status = wk->pin_get<uint8_t>("status", n);
         PS_HIP(hipMemcpyAsync(h_status, bin.d_status.p, (size_t)n, hipMemcpyDeviceToHost, s));
         hipLaunchKernelGGL(k_classify, dim3(std::min((n + 255) / 256, 4096)), dim3(256), 0, s, bin.d_alns.p, bin.aln_cap, bin.d_n_aln.p, bin.d_status.p,
