@@ -317,7 +317,8 @@ PS_COLD bool nt_fetch(const BtArgs &a, NLane &L, BtMem &m, int q)
     L.ctl |= NL_HAVE_CUR;
     L.nsb = 0; L.bm0 = L.bm1 = 0; L.fh = 0xffffu;
     {   // the estimate counts only where it is tighter than the read's own budget (else 255: none -- a read without a hit then needs no second search)
-        const int e = a.cap_est ? (int)a.est[r] : 255;
+        int e = 255;
+        if (a.cap_est) { e = (int)a.est[r] - (a.cap_est - 1); if (e < 0) e = 0; }       // cap_est - 1: subtracted from the estimate (tests: makes it fail, PS_CAP_BIAS)
         L.n_phantom = (uint32_t)(e + md.u_tight < max_units ? e : 255) << 24;
     }
     nt_heads_init(m, md.n_buckets);

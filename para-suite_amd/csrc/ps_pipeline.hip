@@ -718,6 +718,7 @@ static void run_search(Batch &b, const Model &md, int n, const uint32_t *d_bases
     a.order = wide ? nullptr : d_order; a.est = d_est; a.est_ab = d_est_ab;
     // the estimate also spares the search entries (ps_narrow.h, nt_tail): first tier and profile costs only (units == score); a read it fails on starts over without it inside the launch
     a.cap_est = (first_tier && !wide && d_est && md.profile && !(std::getenv("PS_CAP") && std::atoi(std::getenv("PS_CAP")) == 0)) ? 1 : 0;
+    if (a.cap_est) if (const char *e = std::getenv("PS_CAP_BIAS")) a.cap_est += std::max(0, std::min(200, std::atoi(e)));      // tests: estimates too low by that much, so that the restart path runs
     if (const char *e = std::getenv("PS_FETCH_MIN")) a.fetch_min = std::max(1, std::atoi(e));       // tuning: read at every launch
     if (const char *e = std::getenv("PS_HIT_MIN")) a.hit_min = std::max(1, std::atoi(e));
     if (!wide && pool_cap < 65535 && ctx->n_big > 0) {         // large slots for the reads that outgrow their private slice

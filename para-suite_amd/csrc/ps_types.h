@@ -113,7 +113,7 @@ struct BtArgs {
     uint32_t *queue;                                  // next unassigned read (waves take chunks of it)
     const int32_t *order;                             // optional: the read at every queue position (heaviest estimated search first, ps_pipeline.hip run_search); nullptr: position == read
     const uint8_t *est; const uint16_t *est_ab;       // the effort estimate the order was made from (est: the predicted score of the best hit, in budget units); est_ab, optional (profiling): its two scans
-    int cap_est;                                      // first tier, profile costs: children that can only matter if the best hit is worse than est are not stored (ps_narrow.h: nt_tail)
+    int cap_est;                                      // first tier, profile costs: children that can only matter if the best hit is worse than est are not stored (ps_narrow.h: nt_tail); 1 + what tests subtract from est
     uint32_t *read_iters;                             // optional per-read profile (narrow tiers' counting kernel), PS_RI_WORDS words per read: iterations spent | stack slots used |
                                                       // D bound of the whole read, of the seed <<8, the estimate's two scans <<16, <<24 | best score, final budget <<8, hits <<16 | 16 words: the D bounds
     int hit_min;                                      // lanes with a pending hit a wave collects before it records them

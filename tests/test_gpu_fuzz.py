@@ -17,5 +17,9 @@ def test_random_cases_identical_to_oracle(monkeypatch):
     assert fuzz_parity.run(20, 11) == 20
     # ... and with the effort-ordered hand-out (ps_effort.hip; launches below 4,096 reads skip it by default) switched on for the
     # few-thousand-read launches of the sweep: the order of the queue must never show in a result
+    # (with the order comes the estimated best score that spares the search entries in profile mode, ps_narrow.h: nt_tail)
     monkeypatch.setenv("PS_ORDER_MIN", "1")
     assert fuzz_parity.run(20, 12) == 20
+    # ... and with every estimate 8 units too low: most reads start over inside the launch (nt_restart_without_estimate)
+    monkeypatch.setenv("PS_CAP_BIAS", "8")
+    assert fuzz_parity.run(10, 13) == 10

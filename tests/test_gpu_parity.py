@@ -399,3 +399,33 @@ def test_ps_map_reports_errors_without_hanging(mid, workdir):
         del os.environ["PS_CHUNK_MB"]
     with pytest.raises(capi.PsError):
         capi.ps_map(4, "0.04", os.path.join(workdir, "no_such.errorprofile"), None, fa, fq, os.path.join(workdir, "y.sam"))
+
+
+def test_estimated_best_score_spares_entries_and_never_changes_results(ctx_mid, mid, workdir, monkeypatch):
+    """The search kernel leaves out children that can only matter if the read's best hit is worse than the score estimated for it
+    (ps_narrow.h: nt_tail; first tier, profile costs) and starts a read over without the estimate when that fails.  Same hits and
+    SAM as the oracle with the estimate in force, without it (PS_CAP=0) and with estimates made too low by 8 and by 24 units
+    (PS_CAP_BIAS: the restart path runs for most reads); the counting kernel shows that entries were really spared / re-made."""
+    import orc
+    import simulate as S
+    P = S.EXAMPLE_PROFILE.copy()
+    P[3, 1], P[3, 3] = 0.12, 0.87
+    fq = _fastq(mid["genome"], workdir, "cap50", n_reads=12000, read_len=50, seed=77, indel_scale=6.0, n_frac=0.002)
+    ctx_mid.set_profile(P, 2.1e-5, 5.9e-4, -1)
+    opt = orc.profile_opt(P, 2.1e-5, 5.9e-4, -1)
+    pushes = {}
+    ctx_mid.set_stats(True)
+    try:
+        for tag, env in (("cap", {}), ("nocap", {"PS_CAP": "0"}), ("low8", {"PS_CAP_BIAS": "8"}), ("low24", {"PS_CAP_BIAS": "24"})):
+            for k in ("PS_CAP", "PS_CAP_BIAS"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            b = _compare(ctx_mid, mid["orc_index"], opt, fq, workdir, "cap_" + tag, n_check_alns=300)
+            assert b.timing()["n_backtrack_launches"] == 1, tag            # a failed estimate is handled inside the launch
+            pushes[tag] = b.kstats(1)["pushes"]
+    finally:
+        ctx_mid.set_stats(False)
+    print("entries stored:", pushes)
+    assert pushes["cap"] < 0.9 * pushes["nocap"], pushes                 # the estimate spares entries ...
+    assert pushes["low24"] > pushes["cap"], pushes                       # ... and a failed one costs a second search of the read
