@@ -287,6 +287,7 @@ def main():
                     "that many batches, each on its own stream with its own 69-GB workspace, and the search launch of step k+1 is submitted while step k's still runs, "
                     "so that it takes the CUs step k's retiring workgroups leave (tools/backfill_probe.py, tools/pipeline_probe.py).  0 (default) = 2: three in "
                     "flight were measured slower than two at every batch size (1.25 M reads: 280 against 232 ms per step; 10 M: 1230 against 1228)")
+    ap.add_argument("--stagger-ms", type=float, default=-1.0, help="pipelined steps: how long a search launch has the GPU to itself before the next step is started (default: 50 ms per 10 M reads)")
     ap.add_argument("--e2e", type=int, default=1, help="N=1: also time one ps_map call, FASTQ file -> closed SAM file (the reference's own timer scope)")
     ap.add_argument("--dump-hits", default="", help="directory: every rank saves the per-read hit records of its last step (tests)")
     ap.add_argument("--keep", default="")
@@ -480,6 +481,8 @@ def main():
         steps = [None] * n
         done = [False] * n
         stagger = max(0.002, 0.05 * n_mine / 10e6)       # 50 ms behind a 10 M-read launch, in proportion for smaller batches
+        if args.stagger_ms >= 0:
+            stagger = args.stagger_ms * 1e-3
 
         def begin(k):
             if k >= PIPE and not done[k - PIPE]:
