@@ -550,6 +550,7 @@ def main():
         # one sub-batch at a time (nothing overlaps: these launch durations are the kernel alone); the counts of a batch are the
         # same in every pass (the search is deterministic)
         ctx.set_stats(True)
+        cap_was = os.environ.get("PS_CAP")
         os.environ["PS_CAP"] = "0"                  # the counting pass takes the reference's steps: every child upstream stores is stored (the timed kernel leaves
         ks_bt, ks_w, solo_ms = {}, {}, 0.0         # some out on the strength of the estimated best score and searches ~0.002 % of the reads twice: ps_narrow.h, nt_tail)
         for b in batches:
@@ -559,7 +560,10 @@ def main():
                 for k, v in b.kstats(which).items():
                     dst[k] = dst.get(k, 0) + v
         ctx.set_stats(False)
-        del os.environ["PS_CAP"]
+        if cap_was is None:
+            del os.environ["PS_CAP"]
+        else:
+            os.environ["PS_CAP"] = cap_was
         solo_timed_ms = 0.0
         ks_timed = {}
         for b in batches:                   # leave the batches searched with the timed kernel, selected and located (hits below);
@@ -811,6 +815,9 @@ def main():
                     else:
                         argv1 = [bwa, "aln", "-t", str(threads), "-n", mm, fa, fq_all, "-f", sai]
                     argv2 = [bwa, "samse", fa, sai, fq_all, "-f", cold_sam]
+                    # the last warm call has just handed its 74 GB back: the same pause as in front of the warm calls (in the Java's flow the
+                    # SAM -> BAM conversions of the pass before, many seconds, lie between two mapping processes)
+                    time.sleep(6.0)
                     t3 = time.perf_counter()
                     subprocess.run(argv1, check=True, timeout=600)
                     t4 = time.perf_counter()

@@ -372,7 +372,8 @@ void load_reads_chunked(const char *path, int threads, size_t chunk_bytes, const
     ReadSet acc; size_t acc_bytes = 0;
     auto flush = [&]() { if (acc.n) { sink(std::move(acc)); cur = std::min(chunk_bytes, cur * 2); } acc = ReadSet(); acc_bytes = 0; };
     while (!eof || have) {
-        const size_t win = std::min(unit, cur);
+        const size_t fine = std::min<size_t>((size_t)1 << 20, unit);                                  // a piece ends within this of its size
+        const size_t win = std::min(unit, cur > acc_bytes + fine ? cur - acc_bytes : fine);          // the last window of a piece is what is missing to its size
         const size_t want = win > have ? win : have + win;       // what is carried over from a window that could not be cut fills a window alone: it grows
         if (buf.size() < want + 1) buf.resize(want + 1);
         const auto tr0 = std::chrono::steady_clock::now();
@@ -393,7 +394,7 @@ void load_reads_chunked(const char *path, int threads, size_t chunk_bytes, const
             cut = last;
         }
         if (cut) {
-            if (acc_bytes && acc_bytes + cut > cur) flush();                        // this window would take the piece over its size
+            if (acc_bytes && acc_bytes + cut > cur + fine) flush();                 // this window would take the piece well over its size (a window that had to grow)
             const bool first_window = acc.n == 0;
             parse_span(buf.data(), 0, cut, threads, acc);
             if (first_window && acc.n && cur > cut && cur < (~(size_t)0 >> 3)) {     // a piece's arrays are sized once, from what its first window held
@@ -403,7 +404,7 @@ void load_reads_chunked(const char *path, int threads, size_t chunk_bytes, const
                 acc.names.reserve((size_t)(f * (double)acc.names.size()) + 64);
             }
             acc_bytes += cut;
-            if (acc_bytes + win > cur || (hungry && acc_bytes >= hungry_min_bytes && (*hungry)())) flush();
+            if (acc_bytes + fine > cur || (hungry && acc_bytes >= hungry_min_bytes && (*hungry)())) flush();
         }
         std::memmove(buf.data(), buf.data() + cut, have - cut);
         have -= cut;
