@@ -420,7 +420,7 @@ static int map_core(int threads, const char *mm, const char *error_profile, cons
         // ---- piece size from the input
         // Few, large pieces: every search launch ends with its longest read (~0.25 s of a launch are that, whatever its size: a 1.25 M-read
         // launch takes 0.37 s, 10 M reads in one 1.1 s).  The parser hands over what it has when a worker WAITS for work (the first piece
-        // as soon as the index is resident) but not less than 30 % of the input, and otherwise lets a piece grow to 1 GB; with several
+        // as soon as the index is resident) but not less than 20 % of the input, and otherwise lets a piece grow to 1 GB; with several
         // workers a piece is at most 1/(2 x workers) of the input, so that all of them get some.
         size_t chunk_bytes = (size_t)1 << 30, first_bytes = 0, hungry_min = (size_t)128 << 20;
         if (const char *e = std::getenv("PS_CHUNK_MB")) { chunk_bytes = (size_t)std::max(1, std::atoi(e)) << 20; hungry_min = chunk_bytes; }   // stated: taken as it is
@@ -431,7 +431,7 @@ static int map_core(int threads, const char *mm, const char *error_profile, cons
                     const off_t sz = ftello(f);
                     if (sz > 0) {
                         if (n_workers > 1) chunk_bytes = std::min(chunk_bytes, std::max<size_t>((size_t)16 << 20, ((size_t)sz + 2 * (size_t)n_workers - 1) / (2 * (size_t)n_workers) + ((size_t)64 << 10)));   // + slack: cuts fall behind whole records, the last piece must not be a few reads
-                        hungry_min = std::min(chunk_bytes, std::max(hungry_min, (size_t)sz * 3 / 10));
+                        hungry_min = std::min(chunk_bytes, std::max(hungry_min, (size_t)sz / 5));
                         // BAM out: compressing the records (2.3 s per 10 M reads at zlib level 1, 16 threads) is the slowest stage and can only
                         // start on a piece the GPU has finished -- four pieces, so that it starts early (3.5 -> 3.0 s per 10 M reads)
                         if (bam) { chunk_bytes = std::min(chunk_bytes, std::max<size_t>((size_t)64 << 20, (size_t)sz / 4 + ((size_t)64 << 10))); hungry_min = std::min(hungry_min, chunk_bytes / 2); }
