@@ -86,6 +86,12 @@ uint64_t hs_sa(void *p, uint64_t row)
     return (bwtint)steps + sa_sample(s->v, r / (bwtint)s->v.sa_intv);
 }
 
+// the estimated best score of every read for the NEXT hs_aln call (ps_narrow.h, nt_tail: children that can only matter if the best
+// hit is worse than it are not stored; a read whose estimate fails starts over); nullptr: none.  The tests hand in true, too low,
+// too high and random values: the hits must not depend on them.
+static const uint8_t *g_est = nullptr;
+void hs_set_est(const uint8_t *est) { g_est = est; }
+
 // Width stage + backtracking stage for n_reads reads of one length, simulated with n_lanes lanes.
 // codes: [n_reads][len] (0..3, 4 = N).  Outputs: w_out [len+1][n_reads] (pre-shadow), cwb, alns.
 int hs_aln(void *p, const Model *md, int n_reads, int len, const uint8_t *codes, int n_lanes, int pool_cap, int aln_cap, int force_wide, int n_big,
@@ -127,6 +133,7 @@ int hs_aln(void *p, const Model *md, int n_reads, int len, const uint8_t *codes,
     a.w = w.data(); a.cwb = cwb.data(); a.cswb = cswb.data();
     a.alns = alns; a.aln_cap = aln_cap; a.n_aln = n_aln; a.status = status;
     const bool wide = pool_cap > 65535 || force_wide;
+    a.est = g_est; a.cap_est = (g_est && md->profile && !wide) ? 1 : 0; g_est = nullptr;
     std::vector<uint8_t> pool((size_t)n_lanes * pool_cap * (wide ? sizeof(Entry) : sizeof(Entry16)));
     std::vector<uint32_t> heads((size_t)n_lanes * PS_MAX_BUCKETS);
     a.pool = pool.data(); a.pool_cap = (uint32_t)pool_cap; a.heads = heads.data(); a.wide = wide;

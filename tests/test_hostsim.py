@@ -33,6 +33,7 @@ def hs():
     H.hs_model_stock.argtypes = [C.c_char_p, C.c_int, C.c_void_p]
     H.hs_model_profile.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int, C.c_void_p]
     H.hs_aln.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 7
+    H.hs_set_est.argtypes = [C.c_void_p]
     H.hs_index_jump.argtypes = [C.c_void_p, C.c_int]
     H.hs_jump_slot.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p]
     H.hs_banded.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_int]
@@ -110,8 +111,12 @@ def test_occ_blocks_and_sa_walk(hs, sim_index, example):
         assert hs.hs_sa(sim_index, int(k)) == ix.sa(int(k))
 
 
-def _run(hs, h, model, codes, n_lanes=64, pool_cap=4096, aln_cap=64, wide=0, n_big=0):
+def _run(hs, h, model, codes, n_lanes=64, pool_cap=4096, aln_cap=64, wide=0, n_big=0, est=None):
     n, L = codes.shape
+    if est is not None:
+        est = np.ascontiguousarray(est, dtype=np.uint8)
+        assert est.shape == (n,)
+        hs.hs_set_est(est.ctypes.data)          # for the call below only
     alns = np.zeros((n, aln_cap), dtype=ALNREC)
     n_aln = np.zeros(n, dtype=np.int32)
     status = np.zeros(n, dtype=np.uint8)
@@ -243,3 +248,33 @@ def test_rows_above_32_bits_round_trip(hs):
     """33-bit rows (hg19 has 6.27e9): stack entries, block addressing, width saturation, sampled SA with its bit-32 plane."""
     hs.hs_unit_rows33.restype = C.c_int
     assert hs.hs_unit_rows33() == 0
+
+
+@pytest.mark.parametrize("x", [-1, 1])
+def test_estimated_best_score_never_shows_in_the_hits(hs, sim_index, example, x):
+    """ps_narrow.h (nt_tail): with an estimate of a read's best score the lane leaves out children that can only matter if the best
+    hit is worse, and starts the read over without one when the estimate fails.  Whatever the estimate -- exact, too low, too high,
+    zero, random -- hit lists and status equal the run without one (which test_lane_machine_profile compares with the oracle);
+    exact estimates store fewer entries, failed ones cost a second search."""
+    P = S.EXAMPLE_PROFILE.copy()
+    P[3, 1], P[3, 3] = 0.12, 0.87
+    Pc = np.ascontiguousarray(P.reshape(16))
+    sim = S.simulate_reads(example["genome"], 300, 50, seed=41, indel_scale=40, n_frac=0.002)
+    model = (C.c_uint8 * hs.hs_sizeof_model())()
+    assert hs.hs_model_profile(Pc.ctypes.data, 2.1e-5, 5.9e-4, x, 50, model) == 0
+    ks0 = _compare(hs, sim_index, example["orc_index"], orc.profile_opt(P, 2.1e-5, 5.9e-4, x), model, sim["codes"])
+    a0, n0, s0, _ = _run(hs, sim_index, model, sim["codes"])
+    best = np.where(n0 > 0, a0["units"][:, 0], 255).astype(np.int64)
+    rng = np.random.default_rng(9)
+    pushes = {}
+    for tag, est in (("exact", best), ("low", np.maximum(best - 8, 0)), ("high", np.minimum(best + 5, 255)), ("zero", np.zeros_like(best)),
+                     ("random", rng.integers(0, 40, best.size))):
+        a1, n1, s1, ks = _run(hs, sim_index, model, sim["codes"], est=np.clip(est, 0, 255))
+        assert np.array_equal(n1, n0) and np.array_equal(s1, s0), tag
+        for r in range(best.size):
+            assert a1[r, :n1[r]].tobytes() == a0[r, :n0[r]].tobytes(), (tag, r)
+        pushes[tag] = int(ks[3])
+    assert pushes["exact"] <= int(ks0[3]) and pushes["high"] >= pushes["exact"], (pushes, int(ks0[3]))
+    if x == -1:                                  # a budget of several differences: room between the estimate and the budget (-X 1 has none)
+        assert pushes["exact"] < 0.9 * int(ks0[3]), (pushes, int(ks0[3]))
+        assert pushes["zero"] > pushes["exact"], pushes
