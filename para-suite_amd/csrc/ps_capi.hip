@@ -637,7 +637,10 @@ static int map_core(int threads, const char *mm, const char *error_profile, cons
         const double t_written = since();
         if (early_release.joinable()) early_release.join();
         done.clear();
-        close_all();
+        // what is left of the contexts (streams, events, the mapped packed text: 0.05 s) goes the way of the written pieces when the
+        // device memory has been given back already; a failed call and the error-profile pass close them here
+        if (!failed && !sink) { std::vector<ps_ctx *> gone(xs); for (auto &c : xs) c = nullptr; Trash::trash().add(std::thread([gone]() { for (ps_ctx *c : gone) if (c) ps_ctx_close(c); })); }
+        else close_all();
         const double t_closed = since();
         if (failed) return fail(msg);
         if (verbose) {

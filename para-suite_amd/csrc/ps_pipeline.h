@@ -124,7 +124,7 @@ struct Bin {
     std::vector<int32_t> lens; DevBuf<int32_t> d_lens;     // bin-local; d_lens allocated only when ragged
     std::vector<int32_t> ids;                 // global read index of every local read
     DevBuf<uint32_t> bases, nmask, w; DevBuf<uint8_t> cwb, cswb, status; DevBuf<AlnRec> alns; DevBuf<int32_t> n_aln;
-    std::vector<uint32_t> h_bases, h_nmask;   // host copy (tier re-runs gather from it)
+    RawVec<uint32_t> h_bases, h_nmask;        // host copy (tier re-runs gather from it); every word is written by the packing threads, none zero-filled first
     DevBuf<int32_t> d_ids;                     // ids on the device (bin-local -> input order)
     DevBuf<AlnRec> d_alns; DevBuf<int32_t> d_n_aln; DevBuf<uint8_t> d_status; int aln_cap = 0;   // first-tier hit lists stay in HBM
     bool host_alns_valid = false;             // compact host copy, downloaded on demand (tests, ps_batch_alns)

@@ -528,16 +528,26 @@ std::unique_ptr<Batch> batch_prepare(Ctx *ctx, ReadSet &&rs_in, int threads)
         }
         const size_t n = bin.ids.size();
         bin.n_bw = (bin.len + 15) / 16; bin.n_mw = (bin.len + 31) / 32;
-        bin.h_bases.assign((size_t)bin.n_bw * n, 0); bin.h_nmask.assign((size_t)bin.n_mw * n, 0);
+        bin.h_bases.resize((size_t)bin.n_bw * n); bin.h_nmask.resize((size_t)bin.n_mw * n);
+        bin.lens.resize(n);
         {
             const int nt = std::max(1, std::min(threads, 64));
-            auto pack = [&](int t) {                                  // distinct reads write distinct words: no sharing
+            auto pack = [&](int t) {                                  // distinct reads write distinct words: no sharing.  Whole words, bases behind the read's end 0
                 for (size_t r = n * t / nt; r < n * (t + 1) / nt; ++r) {
                     const uint8_t *s = rs.seq.data() + rs.off[bin.ids[r]];
                     const int rl = rs.len[bin.ids[r]];
-                    for (int j = 0; j < rl; ++j) {
-                        if (s[j] > 3) bin.h_nmask[(size_t)(j >> 5) * n + r] |= 1u << (j & 31);
-                        else bin.h_bases[(size_t)(j >> 4) * n + r] |= (uint32_t)s[j] << (2 * (j & 15));
+                    bin.lens[r] = rl;
+                    for (int p = 0; p < bin.n_bw; ++p) {
+                        uint32_t wd = 0;
+                        const int j1 = std::min(rl, 16 * p + 16);
+                        for (int j = 16 * p; j < j1; ++j) if (s[j] <= 3) wd |= (uint32_t)s[j] << (2 * (j & 15));
+                        bin.h_bases[(size_t)p * n + r] = wd;
+                    }
+                    for (int p = 0; p < bin.n_mw; ++p) {
+                        uint32_t wd = 0;
+                        const int j1 = std::min(rl, 32 * p + 32);
+                        for (int j = 32 * p; j < j1; ++j) if (s[j] > 3) wd |= 1u << (j & 31);
+                        bin.h_nmask[(size_t)p * n + r] = wd;
                     }
                 }
             };
@@ -546,8 +556,6 @@ std::unique_ptr<Batch> batch_prepare(Ctx *ctx, ReadSet &&rs_in, int threads)
             pack(0);
             for (auto &x : th) x.join();
         }
-        bin.lens.resize(n);
-        for (size_t r = 0; r < n; ++r) bin.lens[r] = rs.len[bin.ids[r]];
     }
     return b;
 }
