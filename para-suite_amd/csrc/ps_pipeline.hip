@@ -1754,7 +1754,11 @@ void batch_bam_records(const Batch &b, int min_mapq, int threads, std::vector<st
     enc.assign((size_t)nt, std::string()); recs.assign((size_t)nt, std::vector<BamRec>());
     par_for(N, threads, [&](size_t g0, size_t g1, int t) {
         std::string &o = enc[t]; o.reserve((g1 - g0) * 176);
-        for (size_t g = g0; g < g1; ++g) { BamRec r; if (bam_record(b, (int64_t)g, min_mapq, o, r)) recs[t].push_back(r); }
+        const uint8_t *pac = b.ctx->ix.ref.pac_data();
+        for (size_t g = g0; g < g1; ++g) {
+            if (g + 8 < g1 && !(b.h_class[g + 8] & PS_CLS_HOST) && b.h_fin[g + 8].type) __builtin_prefetch(pac + ((size_t)b.h_fin[g + 8].pos >> 2));   // as batch_write_sam
+            BamRec r; if (bam_record(b, (int64_t)g, min_mapq, o, r)) recs[t].push_back(r);
+        }
     });
 }
 
