@@ -3,6 +3,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <deque>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <thread>
@@ -706,6 +707,10 @@ int ps_parse_check(const char *reads_path, int threads, uint64_t chunk_bytes, ui
             n += (uint64_t)rs.n;
         };
         if (chunk_bytes == 0) { ReadSet rs; load_reads(reads_path, rs, threads); eat(rs); }
+        else if (const char *e = std::getenv("PS_PARSE_CHECK_HUNGRY")) {       // tests: a consumer that always waits, as ps_map's GPU worker does at the start: pieces go out at `e` bytes
+            const std::function<bool()> hungry = []() { return true; };
+            load_reads_chunked(reads_path, threads, (size_t)chunk_bytes, [&](ReadSet &&rs) { eat(rs); }, 0, &hungry, (size_t)std::max(1, std::atoi(e)));
+        }
         else load_reads_chunked(reads_path, threads, (size_t)chunk_bytes, [&](ReadSet &&rs) { eat(rs); });
         out[0] = n; out[1] = bases; out[2] = h; out[3] = pieces;
         return 0;

@@ -394,7 +394,7 @@ void load_reads_chunked(const char *path, int threads, size_t chunk_bytes, const
             cut = last;
         }
         if (cut) {
-            const size_t tiny = std::max<size_t>(cur / 8, std::min<size_t>((size_t)32 << 20, cur));            // an end of the input not worth a launch of its own
+            const size_t tiny = cur / 8;                                                                        // an end of the input not worth a launch of its own
             const bool to_the_end = regular && (size_t)std::max<off_t>(0, st.st_size - file_at) + have <= tiny;  // this window and all behind it
             if (acc_bytes && acc_bytes + cut > cur + fine && !to_the_end) flush();    // this window would take the piece well over its size (a window that had to grow)
             const bool first_window = acc.n == 0;

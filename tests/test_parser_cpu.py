@@ -64,3 +64,26 @@ def test_parser_small_inputs(tmp_path):
     assert capi.ps_parse_check(p, 4, 0)[0] == 0 and capi.ps_parse_check(p, 4, 4096)[0] == 0
     with pytest.raises(capi.PsError):
         capi.ps_parse_check(str(tmp_path / "missing.fq"), 1, 0)
+
+
+def test_pieces_by_demand_and_the_end_of_the_input(tmp_path, monkeypatch):
+    """ps_map's parser hands a piece over when the GPU worker waits (here: always) and the piece holds a minimum, lets a piece end at
+    its size rather than at a window boundary, and takes a short end of the input along instead of leaving it as a piece of its
+    own: the same reads whatever the cut, and no small last piece"""
+    rng = np.random.default_rng(6)
+    recs = _records(60000, rng)                # 10.4 MB
+    p = str(tmp_path / "r.fq")
+    _write(p, recs)
+    size = os.path.getsize(p)
+    assert 10_000_000 < size < 10_600_000
+    ref = capi.ps_parse_check(p, 4, 0)
+    plain = capi.ps_parse_check(p, 4, 3_000_000)                       # pieces of 3 MB: 3 + 3 + 3 + 1.4
+    assert plain[:3] == ref[:3] and plain[3] == 4
+    along = capi.ps_parse_check(p, 4, 5_000_000)                       # 5 + 5 + 0.4: the end is less than an eighth of a piece and is taken along
+    assert along[:3] == ref[:3] and along[3] == 2
+    near = capi.ps_parse_check(p, 4, size - 300_000)
+    assert near[:3] == ref[:3] and near[3] == 1
+    monkeypatch.setenv("PS_UNIT_MB", "1")                              # 1-MB windows (64 MB in ps_map)
+    monkeypatch.setenv("PS_PARSE_CHECK_HUNGRY", "1500000")             # a waiting consumer: a piece goes out as soon as it holds 1.5 MB
+    got = capi.ps_parse_check(p, 4, 8 << 20)
+    assert got[:3] == ref[:3] and 5 <= got[3] <= 6, got
