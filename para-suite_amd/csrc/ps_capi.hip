@@ -57,13 +57,20 @@ extern "C" {
 const char *ps_version(void) { return "parasuite-hip 0.1 (gfx950)"; }
 const char *ps_last_error(void) { return g_err.c_str(); }
 
-static ps_ctx *new_ctx(int device)
+// A context in two steps: options and knobs (no device call: ps_map's parser needs nothing else and starts before the runtime is
+// up, which takes 0.2-0.3 s in a fresh process), then the device side (stream, clock).
+static void ctx_attach_device(ps_ctx *x)
 {
-    require_device(device);
-    ps_ctx *x = new ps_ctx();
-    x->c.device = device;
+    require_device(x->c.device);
+    if (x->c.stream) return;
     PS_HIP(hipStreamCreateWithFlags(&x->c.stream, hipStreamNonBlocking));
     PS_HIP(hipEventCreate(&x->c.ref_event)); PS_HIP(hipEventRecord(x->c.ref_event, x->c.stream)); PS_HIP(hipEventSynchronize(x->c.ref_event));
+}
+static ps_ctx *new_ctx(int device, bool attach = true)
+{
+    ps_ctx *x = new ps_ctx();
+    x->c.device = device;
+    if (attach) { try { ctx_attach_device(x); } catch (...) { delete x; throw; } }
     if (const char *e = std::getenv("PS_FETCH_MIN")) x->c.fetch_min = std::atoi(e);       // tuning knobs
     if (const char *e = std::getenv("PS_N_BIG")) x->c.n_big = std::atoi(e);
     if (const char *e = std::getenv("PS_HIT_MIN")) x->c.hit_min = std::atoi(e);
@@ -402,9 +409,9 @@ static int map_core(int threads, const char *mm, const char *error_profile, cons
             std::vector<int> named;
             if (const char *e = std::getenv("PARASUITE_GPU_IDS")) { for (const char *p = e; *p;) { named.push_back(std::atoi(p)); while (*p && *p != ',') ++p; if (*p == ',') ++p; } }
             else {
-                int want = 1, have = 0;
+                int want = 1, have = 1;
                 if (const char *e = std::getenv("PARASUITE_GPUS")) want = std::max(1, std::atoi(e));
-                if (hipGetDeviceCount(&have) != hipSuccess || have < 1) return fail("no HIP device available");
+                if (want > 1 && (hipGetDeviceCount(&have) != hipSuccess || have < 1)) return fail("no HIP device available");   // one device: found out (loudly) when the worker attaches it
                 for (int g = 0; g < std::min(want, have); ++g) named.push_back(g);
             }
             if (named.empty()) named.push_back(0);
@@ -451,7 +458,7 @@ static int map_core(int threads, const char *mm, const char *error_profile, cons
         std::vector<ps_ctx *> xs((size_t)G, nullptr);
         auto close_all = [&]() { for (ps_ctx *c : xs) if (c) ps_ctx_close(c); };
         for (int g = 0; g < G; ++g) {
-            xs[g] = new_ctx(devs[g]);
+            xs[g] = new_ctx(devs[g], false);               // the device side is attached by the device's first worker, beside the parser
             if (error_profile && error_profile[0] ? ps_ctx_set_profile(xs[g], error_profile, indel_profile, mm)
                                                    : ps_ctx_set_stock(xs[g], mm && mm[0] ? mm : "0.04")) { const std::string m = g_err; close_all(); return fail(m); }
             xs[g]->c.host_threads = nthr;
@@ -463,6 +470,7 @@ static int map_core(int threads, const char *mm, const char *error_profile, cons
         std::map<int64_t, std::unique_ptr<Batch>> done; int workers_left = n_workers;
         const size_t done_cap = (size_t)n_workers + 2;   // finished pieces that may wait for the writer
         std::vector<int> index_state((size_t)G, 0);      // 0 not there, 1 resident
+        std::vector<int> attached((size_t)G, 0);         // the device side of the context exists (made by the device's first worker)
         auto fail_all = [&](const std::string &m) { { std::lock_guard<std::mutex> l(mu); if (!failed) { failed = true; msg = m; } } cv.notify_all(); parsed.abort(); };
         double t_parse = 0, t_write = 0, t_release = 0, t_index = 0, t_index_all = 0, t_profile = 0; std::vector<double> t_gpu((size_t)n_workers, 0.0);
         int64_t n_reads = 0, n_pieces = 0;
@@ -556,6 +564,8 @@ static int map_core(int threads, const char *mm, const char *error_profile, cons
         auto worker = [&](int g, int j, int slot) {
             try {
                 Ctx &c = xs[g]->c;
+                if (j == 0) { ctx_attach_device(xs[g]); { std::lock_guard<std::mutex> l(mu); attached[g] = 1; } cv.notify_all(); }
+                else { std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return failed || attached[g] == 1; }); if (failed) return; }
                 require_device(c.device);
                 // The worker's big allocations (69 GB of stack slices + the large slots) are made NOW, on a thread of their own, while the
                 // index loads and the parser works on the first piece: a hipMalloc that is handed memory another call or process has
@@ -618,7 +628,7 @@ static int map_core(int threads, const char *mm, const char *error_profile, cons
         bool have_index = true;
         try {
             if (!index_files_exist(ref_fa)) {         // the Java probes <ref>.bwt and indexes first; be lenient if it did not
-                require_device(xs[0]->c.device);
+                ctx_attach_device(xs[0]);
                 Index tmp; index_build(ref_fa, tmp, xs[0]->c.stream); index_save(tmp, ref_fa);
             }
         } catch (const std::exception &e) { have_index = false; fail_all(e.what()); }
