@@ -1211,6 +1211,7 @@ void batch_select_easy(Batch &b, int threads)
     (void)threads;
     // ---- device: prefix counts of the two draw classes, then every single-best read picks its occurrence ----
     if (b.d_sel.n < (size_t)N) { b.d_sel.alloc((size_t)N); b.d_fin.alloc((size_t)N); b.d_rows.alloc((size_t)N + 1); b.d_pos.alloc((size_t)N + 1); b.d_eb.alloc((size_t)N); b.d_hb.alloc((size_t)N); }
+    const double ms_alloc = ms_since(t0);
     {
         uint32_t *f1 = wk->ws_get<uint32_t>("flag1", (size_t)N), *f2 = wk->ws_get<uint32_t>("flag2", (size_t)N);
         hipLaunchKernelGGL(k_class_flags, dim3(2048), dim3(256), 0, s, b.d_class.p, (long long)N, f1, f2);
@@ -1231,6 +1232,7 @@ void batch_select_easy(Batch &b, int threads)
         a.sel = b.d_sel.p; a.rows = b.d_rows.p; a.err = d_err;
         hipLaunchKernelGGL(k_select, dim3(std::min((a.n + 255) / 256, 4096)), dim3(256), 0, s, a);
     }
+    const double ms_launch = ms_since(t0);
     // ---- host: the subset (its class-1 members by the same offset algebra, then the alternative-hit lists) ----
     const int n_occ = ctx->opt.n_occ;
     b.multis.clear();
@@ -1281,10 +1283,13 @@ void batch_select_easy(Batch &b, int threads)
             }
         });
     }
+    const double ms_host = ms_since(t0);
     int err = 0;
     PS_HIP(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, s));
     PS_HIP(hipStreamSynchronize(s));
     if (err) throw Error("tie-break stream hit the zero state; sequential replay required");
+    if (const char *e = std::getenv("PS_VERBOSE")) if (std::atoi(e) >= 3)
+        std::fprintf(stderr, "[parasuite-hip]     select_easy of %lld reads: allocations %.1f ms, launches until %.1f, host part until %.1f, device done at %.1f ms\n", (long long)N, ms_alloc, ms_launch, ms_host, ms_since(t0));
     b.selected = true;
     b.tm.ms_select += ms_since(t0); b.tm.ms_sel_easy = ms_since(t0);
 }

@@ -29,7 +29,7 @@ configs = [dict(PS_WORKERS_PER_GPU=str(w)) for w in workers] + [dict(kv.split('=
 for cfg, rep in [(c, r) for c in configs for r in range(2)]:
     os.environ.update(cfg)
     print(' '.join('%s=%s' % kv for kv in cfg.items()), flush=True)
-    t = time.time(); os.environ['PS_VERBOSE']='2'; capi.ps_map(16, '-1', '/tmp/e2e.errorprofile', '/tmp/e2e.indelprofile', fa, fq, '/tmp/e2e.sam'); dt = time.time() - t
+    t = time.time(); os.environ['PS_VERBOSE']=os.environ.get('E2E_VERBOSE','2'); capi.ps_map(16, '-1', '/tmp/e2e.errorprofile', '/tmp/e2e.indelprofile', fa, fq, '/tmp/e2e.sam'); dt = time.time() - t
     print('ps_map (index load + %d reads + SAM written) %.2fs = %.2f M reads/s, SAM %.0f MB' % (n, dt, n / dt / 1e6, os.path.getsize('/tmp/e2e.sam') / 1e6), flush=True)
     if rep == 1:
         for k in cfg: os.environ.pop(k, None)
