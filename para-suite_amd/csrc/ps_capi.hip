@@ -78,7 +78,7 @@ static ps_ctx *new_ctx(int device, bool attach = true)
     if (std::getenv("PS_KSTATS")) x->c.want_kstats = true;
     if (const char *e = std::getenv("PS_BT_BLOCKS")) x->c.bt_blocks = std::atoi(e);
     if (const char *e = std::getenv("PS_POOL_CAP")) x->c.pool_cap[0] = (uint32_t)std::atoi(e);
-    if (const char *e = std::getenv("PS_ALN_CAP")) x->c.aln_cap[0] = std::max(1, std::atoi(e));           // hit intervals a read may list in the first tier
+    if (const char *e = std::getenv("PS_ALN_CAP")) { x->c.aln_cap[0] = std::max(1, std::atoi(e)); x->c.aln_cap_short = 0; }   // hit intervals a read may list in the first tier (stated: for every length)
     return x;
 }
 
@@ -201,6 +201,7 @@ int ps_ctx_set_tiers(ps_ctx *x, const uint32_t pool_cap[3], const int32_t aln_ca
 {
     PS_TRY
         for (int t = 0; t < 3; ++t) { if (pool_cap) x->c.pool_cap[t] = pool_cap[t]; if (aln_cap) x->c.aln_cap[t] = aln_cap[t]; }
+        if (aln_cap) x->c.aln_cap_short = (aln_cap[0] == 8) ? 32 : 0;                  // stated sizes hold for every length; the default gets its short-read rule back
         x->c.bt_blocks = bt_blocks; return 0;
     PS_CATCH_INT
 }

@@ -101,6 +101,8 @@ struct Ctx {
     int bt_blocks = 0;             // grid of the backtracking kernel (0 = 4 blocks per CU)
     uint32_t pool_cap[3] = {16384, 65535, 2000064};   // stack entries per lane: 16-byte narrow tiers, then the wide tier
     int aln_cap[3] = {8, 256, 65536};
+    int aln_cap_short = 32;        // first tier, bins whose longest read has at most 40 bases (adapter-trimmed PAR-CLIP reads, the transcript pass): short reads
+                                   // hit many places by chance -- 1.7 % of 18-40 bp reads list more than 8 intervals, 0.3 % more than 32; 0 = as aln_cap[0]
     bool want_kstats = false;      // search kernel with counters (KStats of the backtracking stage): measurement runs only
     bool want_read_iters = false; std::vector<uint32_t> read_iters;   // profiling aid: last launch's per-read profile (ps_types.h: BtArgs::read_iters), PS_RI_WORDS words per read, in the order the launch held the reads (a bin's leading-base order)
     int n_big = 4096;              // 1 MB stack slots a launch may hand to reads that outgrow their private slice

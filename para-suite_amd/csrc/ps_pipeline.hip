@@ -1010,8 +1010,9 @@ void batch_search(Batch &b)
     for (Bin &bin : b.bins) {
         const int n = (int)bin.ids.size();
         bin.host_alns_valid = false;
-        if (bin.d_alns.n < (size_t)n * ctx->aln_cap[0]) { bin.d_alns.alloc((size_t)n * ctx->aln_cap[0]); bin.d_n_aln.alloc(n); bin.d_status.alloc(n); }
-        bin.aln_cap = ctx->aln_cap[0];
+        const int cap1 = (bin.len <= 40 && ctx->aln_cap_short > ctx->aln_cap[0]) ? ctx->aln_cap_short : ctx->aln_cap[0];
+        if (bin.d_alns.n < (size_t)n * cap1 || bin.aln_cap != cap1) { bin.d_alns.alloc((size_t)n * cap1); bin.d_n_aln.alloc(n); bin.d_status.alloc(n); }
+        bin.aln_cap = cap1;
         run_search(b, bin.md, n, bin.bases.p, bin.nmask.p, bin.ragged ? bin.d_lens.p : nullptr, ctx->pool_cap[0], bin.aln_cap, bin.d_alns.p, bin.d_n_aln.p, bin.d_status.p, true);
         uint8_t *h_status = wk->pin_get<uint8_t>("status", n);
         PS_HIP(hipMemcpyAsync(h_status, bin.d_status.p, (size_t)n, hipMemcpyDeviceToHost, s));
