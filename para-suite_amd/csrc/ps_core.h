@@ -621,7 +621,7 @@ PS_HD void bt_iter(const BtArgs &a, const BtHot &h, BtLane &L, BtMem &m, int fet
             bool eq = (m.cw[i] & 0x80) != 0;
             if (b1 > mleft - 1) allow_diff = false;
             else if (b1 == mleft - 1 && b0 == mleft - 1 && eq) allow_M = false;
-            if (h.use_seed()) {
+            if (h.use_seed() && len > h.seed_len()) {            // the read's own seed rule
                 int ii = i - (len - h.seed_len());
                 if (ii > 0) {
                     int s1 = m.csw[ii - 1] & 0x7f, s0 = m.csw[ii] & 0x7f;

@@ -46,6 +46,7 @@ __global__ void __launch_bounds__(256) k_width(WidthArgs a)
         WChain A, B;
         wchain_init(a.ix, A); wchain_init(a.ix, B);
         const int len = a.lens ? a.lens[r] : a.len, seed_len = a.seed_len;
+        const bool seeded = a.use_seed && len > seed_len;     // the seed rule is the read's own: a launch may hold reads on either side of the seed length
         uint32_t bw = 0, mw = 0, sbw = 0, smw = 0;  // current base / N-mask words of the two chains
         uint32_t cww = 0, csww = 0;                  // compact width bytes being assembled, 4 positions per word
         for (int i = 0; i < len; ++i) {
@@ -54,7 +55,7 @@ __global__ void __launch_bounds__(256) k_width(WidthArgs a)
             if (i == 0 || (j & 31) == 31) mw = a.nmask[(size_t)(j >> 5) * a.n_reads + r];
             int base = ((mw >> (j & 31)) & 1u) ? 4 : (int)((bw >> (2 * (j & 15))) & 3u);
             uint32_t wv; uint8_t cb;
-            if (a.use_seed && i < seed_len) {
+            if (seeded && i < seed_len) {
                 int js = seed_len - 1 - i;
                 if (i == 0 || (js & 15) == 15) sbw = a.bases[(size_t)(js >> 4) * a.n_reads + r];
                 if (i == 0 || (js & 31) == 31) smw = a.nmask[(size_t)(js >> 5) * a.n_reads + r];
@@ -72,9 +73,11 @@ __global__ void __launch_bounds__(256) k_width(WidthArgs a)
         a.w[(size_t)len * a.n_reads + r] = 0;
         cww |= (uint32_t)cw_pack(A.bid + 1, false) << (8 * (len & 3));
         a.cwb[(size_t)(len >> 2) * a.n_reads + r] = cww;
-        if (a.use_seed) {
+        if (seeded) {
             csww |= (uint32_t)cw_pack(B.bid + 1, false) << (8 * (seed_len & 3));
             a.cswb[(size_t)(seed_len >> 2) * a.n_reads + r] = csww;
+        } else if (a.use_seed) {                     // a read without a seed in a launch with one: its seed bounds are never looked at, but the lane loads the words
+            for (int p = 0; p <= (seed_len >> 2); ++p) a.cswb[(size_t)p * a.n_reads + r] = 0u;
         }
     }
     flush_stats(a.stats, st);
@@ -264,7 +267,7 @@ __global__ void __launch_bounds__(256, PS_BT_WAVES) k_backtrack_n(const BtArgs *
             if (mode == M_FETCH && now != M_FETCH && now != M_EXIT) {       // a read was taken: its lower bounds as the width stage left them
                 iters0 = st.iters - 1u;
                 const int len = nl_len(L), sl = h.seed_len();
-                a.read_iters[PS_RI_WORDS * (size_t)L.r + 2] = (uint32_t)(m.cw[len - 1] & 0x7f) | ((h.use_seed() && sl > 0 && sl <= len ? (uint32_t)(m.csw[sl - 1] & 0x7f) : 0u) << 8) | (a.est_ab ? (uint32_t)a.est_ab[L.r] << 16 : 0u);
+                a.read_iters[PS_RI_WORDS * (size_t)L.r + 2] = (uint32_t)(m.cw[len - 1] & 0x7f) | ((h.use_seed() && sl > 0 && sl < len ? (uint32_t)(m.csw[sl - 1] & 0x7f) : 0u) << 8) | (a.est_ab ? (uint32_t)a.est_ab[L.r] << 16 : 0u);
                 const uint32_t *cw32 = reinterpret_cast<const uint32_t *>(m.cw);        // words 4..19: the D bounds themselves (bid | eq << 7 per position), 64 positions
                 for (int p = 0; p < 16; ++p) a.read_iters[PS_RI_WORDS * (size_t)L.r + 4 + p] = p < lm_ncw(len) ? cw32[p] : 0u;
             }

@@ -434,7 +434,7 @@ PS_HD void nt_step_occ(const BtHot &h, NLane &L, LaneStats &st, BtMem &m, NtStep
     q.i = i;
     q.cw_i = m.cw[i]; q.cw_im1 = m.cw[i > 0 ? i - 1 : 0];
     const int ii = i - (len - h.seed_len());
-    q.in_seed = h.use_seed() && ii > 0;
+    q.in_seed = h.use_seed() && len > h.seed_len() && ii > 0;      // the read's own seed rule (upstream: a read no longer than the seed has none)
     q.cs_i = q.in_seed ? m.csw[ii] : 0u; q.cs_im1 = q.in_seed ? m.csw[ii - 1] : 0u;
     q.s = nt_seq_at(m, L, i, len, max_len);
     const int depth = nt_depth(len, L.wa, L.wb);

@@ -483,7 +483,8 @@ std::unique_ptr<Batch> batch_prepare(Ctx *ctx, ReadSet &&rs_in, int threads)
             // the packed word count and where the N mask lives follow the read (budget: BtArgs::units_by_len) or the longest read of
             // the bin (local-memory layout), so that adapter-trimmed input with dozens of lengths is ONE launch where it used to be
             // one per budget step -- every launch ends with ~0.2 s of emptying machine
-            const std::vector<int> key = {md.max_gapo, md.use_seed, md.seed_len};
+            const std::vector<int> key = {md.max_gapo};      // the seed rule follows the read too (len > seed_len, checked per read by the kernels) since adapter-trimmed
+                                                             // PAR-CLIP reads lie on both sides of the 32-base seed: 18-40 bp input is one launch, not two
             auto bc = bin_of_class.find(key);
             if (bc == bin_of_class.end()) { bc = bin_of_class.emplace(key, (int)b->bins.size()).first; b->bins.emplace_back(); }
             cls = class_of_len[(size_t)len] = bc->second;
