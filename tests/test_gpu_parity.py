@@ -429,3 +429,24 @@ def test_estimated_best_score_spares_entries_and_never_changes_results(ctx_mid, 
     print("entries stored:", pushes)
     assert pushes["cap"] < 0.9 * pushes["nocap"], pushes                 # the estimate spares entries ...
     assert pushes["low24"] > pushes["cap"], pushes                       # ... and a failed one costs a second search of the read
+
+
+@pytest.mark.parametrize("mode", ["stock", "profile"])
+def test_lengths_on_both_sides_of_the_seed_share_a_launch(ctx_mid, mid, workdir, mode):
+    """adapter-trimmed PAR-CLIP reads of 18-44 bases: upstream gives a read no longer than the 32-base seed no seed rule; the
+    kernels test that per read (len > seed_len), so that both kinds are ONE launch -- SAM and hit lists == oracle"""
+    import orc
+    import simulate as S
+    fq = _fastq(mid["genome"], workdir, "seedmix", n_reads=6000, read_len=44, min_len=18, seed=314, indel_scale=6.0, n_frac=0.003)
+    if mode == "stock":
+        ctx_mid.set_stock("0.04")
+        opt = orc.stock_opt("0.04")
+    else:
+        P = S.EXAMPLE_PROFILE.copy()
+        P[3, 1], P[3, 3] = 0.12, 0.87
+        ctx_mid.set_profile(P, 2.1e-5, 5.9e-4, -1)
+        opt = orc.profile_opt(P, 2.1e-5, 5.9e-4, -1)
+    b = _compare(ctx_mid, mid["orc_index"], opt, fq, workdir, "seedmix_" + mode, n_check_alns=400)
+    tm = b.timing()
+    if mode == "profile":                      # one gap limit for every length: one bin, one first-tier launch (+ one per larger tier that was needed)
+        assert tm["n_backtrack_launches"] == 1 + (tm["n_overflow_tier1"] > 0) + (tm["n_overflow_tier2"] > 0), tm
